@@ -1,0 +1,147 @@
+/*
+ * kpgnn.h - C ABI of libkpgnn_hip.so: the MI355X (gfx950) K-hop message-passing hot path of KP-GNN.
+ *
+ * This is the drop-in boundary.  The reference (JiaruiFeng/KP-GNN) is pure Python; the arithmetic of
+ * this path lives in its layer files and in PyG's MessagePassing.propagate.  Each entry point below
+ * names the reference code it replaces.  Signatures carry plain pointers, sizes and strides only (no
+ * torch types); every pointer marked "device" is HBM memory owned by the caller; nothing is allocated,
+ * freed or synchronised inside a call, so calls are HIP-graph capturable.  `stream` is a hipStream_t
+ * passed as void*.  All entry points return 0 on success and a negative KPGNN_E* code on failure;
+ * kpgnn_last_error() returns a thread-local message for the last failure.
+ *
+ * Tensor layout conventions: N nodes of the collated batch, K hop slots, D per-hop feature width.
+ * Feature tensors are fp32, logical shape [N, K, D], innermost dimension contiguous, node and hop
+ * strides given in ELEMENTS (so a [N,k,H] view of a history buffer or of a [N, K*dk] matrix needs no copy).
+ *
+ * K-hop CSR ("khop_csr"): the K-hop edge list (edge_index [2,E] int64, edge_attr [E,K] int64 where
+ * attr==0 means "edge not active in this hop", reference data_utils.py:80-93) is re-laid out once per
+ * batch as a CSR keyed by (node, hop): segment s = node*K + hop holds the active (edge,hop) pairs of that
+ * node in ORIGINAL EDGE ORDER (stable), as parallel arrays col[] (the other endpoint, int32) and code[]
+ * (the attr value = embedding row, uint16).  Two orientations are built: by destination (forward
+ * aggregation) and by source (backward).
+ */
+#ifndef KPGNN_H_
+#define KPGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPGNN_ABI_VERSION 1
+
+#define KPGNN_OK 0
+#define KPGNN_EINVAL (-1)   /* bad argument (shape, stride, null pointer, limits) */
+#define KPGNN_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define KPGNN_ELIMIT (-3)   /* size exceeds an implementation limit (int32 indices, LDS) */
+
+typedef void* kpgnn_stream_t; /* hipStream_t */
+
+int kpgnn_abi_version(void);
+const char* kpgnn_last_error(void);
+
+/* Device facts used by the host side for launch sizing / roofline reporting (needs a GPU). */
+int kpgnn_device_info(int* cu_count, int* lds_bytes_per_block, int* wavefront, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * K-hop CSR construction (device).  Replaces nothing in the reference one-to-one: the reference feeds
+ * the raw edge list to PyG (`self.propagate(edge_index, ...)`, layers/KPGIN.py:100, KPGINplus.py:74,
+ * KPGCN.py:110, gine.py:52) which gathers/scatters over all E*K (edge,hop) slots and multiplies the
+ * inactive ones by a zero mask (message(): KPGIN.py:115-118).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Pass 1: statistics of a K-hop edge list.  stats (device, int64[8]) receives
+ *   [0] A = number of active (edge,hop) pairs   [1] max attr in column 0   [2] max attr in columns 1..K-1
+ *   [3] min attr over all columns               [4] min node index         [5] max node index
+ * edge_index rows are `ei_stride` elements apart; edge_attr rows `attr_stride` elements apart. */
+int kpgnn_csr_stats(const int64_t* edge_index, int64_t ei_stride, const int64_t* edge_attr, int64_t attr_stride,
+                    int64_t E, int32_t K, int64_t* stats, kpgnn_stream_t stream);
+
+/* Workspace (bytes, device) needed by kpgnn_csr_build for E edges, A active pairs, N nodes, K hops. */
+size_t kpgnn_csr_workspace_bytes(int64_t E, int64_t A, int64_t N, int32_t K);
+
+/* Pass 2: build both orientations.  A must be stats[0].  Outputs (device):
+ *   rowptr_dst int32[N*K+1], col_dst int32[A] (= source node), code_dst uint16[A]   -- keyed by (dst,hop)
+ *   rowptr_src int32[N*K+1], col_src int32[A] (= dest node),   code_src uint16[A]   -- keyed by (src,hop)
+ * Entries of one segment keep the order of the input edge list (stable), which is the reference's CPU
+ * summation order (index_add_ over edges in order). */
+int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t* edge_attr, int64_t attr_stride,
+                    int64_t E, int32_t K, int64_t N, int64_t A,
+                    int32_t* rowptr_dst, int32_t* col_dst, uint16_t* code_dst,
+                    int32_t* rowptr_src, int32_t* col_src, uint16_t* code_src,
+                    void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused K-hop aggregation.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    KPGNN_MODE_GIN = 0,     /* out = S + P + (1+eps)*x                  KPGIN.py:100-105, gine.py:52-53 */
+    KPGNN_MODE_GINPLUS = 1, /* out = gelu(S) + P                        KPGINplus.py:74-77,87-88        */
+    KPGNN_MODE_GCN = 2,     /* out = relu(S_norm) + P, self loops + sym. degree norm  KPGCN.py:85-114,120-126 */
+    KPGNN_MODE_SUM = 3      /* out = S (+P), no activation: building block / KGINConv run_simulation.py:73 */
+};
+/* where, for node i and hop k,  S[i,k,:] = sum over active pairs a of segment (i,k) of
+ *      x[col[a], k, :] + table_k[code[a], :]          (table_0 = hop1_edge_emb, table_k>0 = hopk_edge_emb)
+ * and for GCN each term is scaled by dis[col[a],k]*dis[i,k] and the self loop (code 1) is added,
+ * dis = (segment length + 1)^-1/2  (KPGCN.py:11-25,106-109).  P = peripheral_attr (nullable). */
+
+typedef struct kpgnn_agg_fwd_desc {
+    int32_t N, K, D;            /* nodes, ACTIVE hop slots (k <= K_csr), per-hop width */
+    int32_t K_csr;              /* hop slots per node in rowptr (GNNPlus layer l<K uses a prefix, GNNs.py:429) */
+    int32_t mode;               /* KPGNN_MODE_* */
+    int32_t n_code0, n_codek;   /* rows of table0 / tablek (codes are validated against these by the caller) */
+    int32_t use_tables;         /* 0: mask-only aggregation (no edge-code embedding; run_simulation.py:87-90) */
+    const int32_t* rowptr;      /* device, [N*K_csr+1]  (by destination) */
+    const int32_t* col;         /* device, [A] */
+    const uint16_t* code;       /* device, [A] */
+    const float* dis;           /* device, [N*K_csr] deg^-1/2, GCN only (else NULL) */
+    const float* x;             /* device, [N,K,D] */
+    int64_t x_sn, x_sk;
+    const float* table0;        /* device, [n_code0, D] contiguous */
+    const float* tablek;        /* device, [n_codek, D] contiguous (NULL iff K_csr == 1) */
+    const float* periph;        /* device, [N,K,D] or NULL */
+    int64_t p_sn, p_sk;
+    const float* eps;           /* device scalar (GIN) or NULL (== 0) */
+    float* out;                 /* device, [N,K,D] */
+    int64_t o_sn, o_sk;
+    float* pre;                 /* device, [N,K,D] contiguous or NULL: S before the activation (saved for bwd) */
+    /* Optional fused geometric hop-combine (combine.py:43-58): if theta != NULL, `out` is not written;
+     * hout[i,:] = sum_k theta[k,:] * (act(S[i,k,:]) + P[i,k,:]) is.  theta: device [K, D]. */
+    const float* theta;
+    float* hout;                /* device, [N, D] contiguous */
+    /* Optional constant row added to every x row of hops >= 1 (gathered and self terms): the reference's
+     * `x[:, 1:] += hopk_node_path_emb(pe_attr)` (KPGIN.py:92-94) when pe_attr is all padding (always so for
+     * the reference's own pre-transform, data_utils.py:91,123): xbias = that table's row 0.  device [D]. */
+    const float* xbias;
+} kpgnn_agg_fwd_desc;
+
+int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
+
+/* Backward of the aggregation w.r.t. x and the two edge-code tables, given g = dL/dS [N,K,D]
+ * (the caller applies the activation derivative; for GCN g already includes relu').
+ *   gx[j,k,:]      = sum over pairs a of segment (j,k) of the BY-SOURCE csr of w_a * g[col[a],k,:]  (+ self terms)
+ *   gtable_k[c,:] += sum over pairs with code c of w_a * g[col[a],k,:]      (fp32 atomics; caller zeroes)
+ * self terms: GIN adds (1+eps)*g[j,k,:]; GCN adds dis[j,k]^2*g[j,k,:] and the same into gtable_k[1,:]. */
+typedef struct kpgnn_agg_bwd_desc {
+    int32_t N, K, D, K_csr, mode, n_code0, n_codek, use_tables;
+    const int32_t* rowptr_src;
+    const int32_t* col_src;
+    const uint16_t* code_src;
+    const float* dis;           /* GCN only */
+    const float* g;             /* device [N,K,D] */
+    int64_t g_sn, g_sk;
+    const float* eps;
+    float* gx;                  /* device [N,K,D] */
+    int64_t gx_sn, gx_sk;
+    float* gtable0;             /* device [n_code0, D], accumulated into (NULL: skip table grads) */
+    float* gtablek;             /* device [n_codek, D] */
+} kpgnn_agg_bwd_desc;
+
+int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPGNN_H_ */

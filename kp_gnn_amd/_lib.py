@@ -1,0 +1,87 @@
+"""ctypes binding of libkpgnn_hip.so (include/kpgnn.h).  There is NO fallback: if the library is missing
+or a call fails, an exception is raised - the product path never silently runs on the CPU."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "libkpgnn_hip.so")
+
+MODE_GIN, MODE_GINPLUS, MODE_GCN, MODE_SUM = 0, 1, 2, 3
+
+c_i32, c_i64, c_f32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+
+
+class KpgnnError(RuntimeError):
+    pass
+
+
+class AggFwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("K_csr", c_i32), ("mode", c_i32),
+        ("n_code0", c_i32), ("n_codek", c_i32), ("use_tables", c_i32),
+        ("rowptr", c_vp), ("col", c_vp), ("code", c_vp), ("dis", c_vp),
+        ("x", c_vp), ("x_sn", c_i64), ("x_sk", c_i64),
+        ("table0", c_vp), ("tablek", c_vp),
+        ("periph", c_vp), ("p_sn", c_i64), ("p_sk", c_i64),
+        ("eps", c_vp),
+        ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
+        ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
+    ]
+
+
+class AggBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("K_csr", c_i32), ("mode", c_i32),
+        ("n_code0", c_i32), ("n_codek", c_i32), ("use_tables", c_i32),
+        ("rowptr_src", c_vp), ("col_src", c_vp), ("code_src", c_vp), ("dis", c_vp),
+        ("g", c_vp), ("g_sn", c_i64), ("g_sk", c_i64),
+        ("eps", c_vp),
+        ("gx", c_vp), ("gx_sn", c_i64), ("gx_sk", c_i64),
+        ("gtable0", c_vp), ("gtablek", c_vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/kpgnn.h declares
+SIGNATURES = {
+    "kpgnn_abi_version": (ctypes.c_int, []),
+    "kpgnn_last_error": (ctypes.c_char_p, []),
+    "kpgnn_device_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.c_char_p, ctypes.c_int]),
+    "kpgnn_csr_stats": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "kpgnn_csr_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i64, c_i64, c_i32]),
+    "kpgnn_csr_build": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_i64,
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
+    "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises KpgnnError when the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or HIP_LIB_PATH
+    if not os.path.exists(path):
+        raise KpgnnError(
+            f"{path} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m kp_gnn_amd.build` (or __graft_entry__.build()).")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise KpgnnError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kpgnn_abi_version() != 1:
+        raise KpgnnError("libkpgnn_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().kpgnn_last_error()
+        raise KpgnnError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

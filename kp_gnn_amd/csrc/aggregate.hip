@@ -1,0 +1,457 @@
+// Fused K-hop aggregation for gfx950 (MI355X): forward and backward of
+//     S[i,k,:] = sum_{a in segment(i,k)} ( x[col[a],k,:] + table_k[code[a],:] )
+// plus the per-layer epilogue (peripheral add, (1+eps)x / GELU / ReLU + symmetric degree norm) and the
+// optional geometric hop-combine.  Replaces the reference's materialised [E,K,D] chain
+//   embedding -> index_select -> add -> masked_fill_ -> scatter-sum     (layers/KPGIN.py:90-118,
+//   KPGINplus.py:64-88, KPGCN.py:96-126, gine.py:49-59; PyG MessagePassing.propagate).
+//
+// Mapping (wave = 64 lanes): a SUB-GROUP of G lanes (G = pow2 >= D/VEC) owns one node and walks its
+// hop segments in order; lanes span the D feature columns with VEC-wide (up to 16 B) accesses, so one
+// neighbour row is one coalesced burst.  Neighbour ids/codes of a segment are loaded G at a time by
+// the sub-group (coalesced) and broadcast with ds_bpermute; rows are gathered 4 deep.  The two
+// edge-code embedding tables live in LDS.  Summation order inside a segment is the edge-list order
+// (the CPU reference's index_add_ order), so results are run-to-run deterministic.
+//
+// HBM-bound: per launch the algorithmic traffic is x + P + out (+pre) once, ids/codes once, tables once
+// (DESIGN.md "Algorithmic bytes").  The gather re-reads (A*D*4 bytes) are meant to be served by L2:
+// tiles of consecutive nodes (= same graph) are walked per XCD (kpgnn_common.h XcdTileWalk).
+#include <initializer_list>
+
+#include "kpgnn_common.h"
+
+namespace kpgnn {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxLdsTableBytes = 96 * 1024;
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { using T = float; };
+template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<4> { using T = float4; };
+
+template <int VEC> struct V {
+    float v[VEC];
+    __device__ __forceinline__ static V zero() { V r; for (int i = 0; i < VEC; ++i) r.v[i] = 0.f; return r; }
+    __device__ __forceinline__ static V load(const float* p) {
+        V r;
+        typename Vec<VEC>::T t = *reinterpret_cast<const typename Vec<VEC>::T*>(p);
+        const float* f = reinterpret_cast<const float*>(&t);
+        for (int i = 0; i < VEC; ++i) r.v[i] = f[i];
+        return r;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        typename Vec<VEC>::T t;
+        float* f = reinterpret_cast<float*>(&t);
+        for (int i = 0; i < VEC; ++i) f[i] = v[i];
+        *reinterpret_cast<typename Vec<VEC>::T*>(p) = t;
+    }
+    __device__ __forceinline__ void add(const V& o) { for (int i = 0; i < VEC; ++i) v[i] += o.v[i]; }
+    __device__ __forceinline__ void fma(float s, const V& o) { for (int i = 0; i < VEC; ++i) v[i] = fmaf(s, o.v[i], v[i]); }
+};
+
+__device__ __forceinline__ float gelu_exact(float x) {  // F.gelu(approximate='none')
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+struct FwdParams {
+    int N, K, D, K_csr, n_code0, n_codek, mode, combine;
+    const int32_t* rowptr;
+    const int32_t* col;
+    const uint16_t* code;
+    const float* dis;
+    const float* x; int64_t x_sn, x_sk;
+    const float* table0;
+    const float* tablek;
+    const float* periph; int64_t p_sn, p_sk;
+    const float* eps;
+    float* out; int64_t o_sn, o_sk;
+    float* pre;
+    const float* theta;
+    float* hout;
+    const float* xbias;
+};
+
+// TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
+// GCN selects the weighted inner loop; the other epilogues are wave-uniform runtime switches.
+template <int VEC, int G, bool GCN, int TAB>
+__global__ void __launch_bounds__(kBlock)
+agg_fwd_kernel(const FwdParams p) {
+    const int MODE = p.mode;
+    const bool COMBINE = p.combine != 0;
+    extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+    const int D = p.D;
+    if (TAB == 1) {
+        const int n0 = p.n_code0 * D, nk = p.n_codek * D;
+        for (int t = threadIdx.x; t < n0; t += kBlock) lds_tab[t] = p.table0[t];
+        for (int t = threadIdx.x; t < nk; t += kBlock) lds_tab[n0 + t] = p.tablek[t];
+        __syncthreads();
+    }
+    const float* tab0 = TAB == 1 ? lds_tab : p.table0;
+    const float* tabk = TAB == 1 ? lds_tab + p.n_code0 * D : p.tablek;
+
+    constexpr int NODES = kBlock / G;       // nodes per tile
+    const int sg = threadIdx.x / G;
+    const int sl = threadIdx.x % G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sg_lane0 = lane - sl;        // first lane of this sub-group inside its wave
+    const int c0 = sl * VEC;
+    const bool col_ok = c0 < D;
+    const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
+    const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+
+    for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
+        const int64_t i = w.cur * NODES + sg;
+        if (i >= p.N) continue;             // whole sub-group leaves together
+        const int32_t* rp = p.rowptr + i * p.K_csr;
+        V<VEC> hsum = V<VEC>::zero();
+        int beg = rp[0];
+        for (int k = 0; k < p.K; ++k) {
+            const int end = rp[k + 1];
+            const float* xk = p.x + (int64_t)k * p.x_sk + c0;
+            const float* tab = k == 0 ? tab0 : tabk;
+            V<VEC> acc = V<VEC>::zero();
+            float wacc = 0.f;  // GCN: sum of edge weights of the segment (for the constant x-bias term)
+            for (int base = beg; base < end; base += G) {
+                const int idx = base + sl;
+                int myj = 0, myc = 0;
+                if (idx < end) {
+                    myj = p.col[idx];
+                    if (TAB != 0) myc = p.code[idx];
+                }
+                float myw = 1.0f;
+                if (GCN && idx < end) myw = p.dis[(int64_t)myj * p.K_csr + k];
+                const int cnt = min(G, end - base);
+                for (int t = 0; t < cnt; t += 4) {
+                    int j[4], c[4]; float wgt[4]; V<VEC> r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
+                        j[u] = __shfl(myj, srcl);
+                        if (TAB != 0) c[u] = __shfl(myc, srcl);
+                        if (GCN) wgt[u] = __shfl(myw, srcl);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        r[u] = V<VEC>::zero();
+                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(xk + (int64_t)j[u] * p.x_sn);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (t + u < cnt && col_ok) {
+                            if (TAB != 0) r[u].add(V<VEC>::load(tab + c[u] * D + c0));
+                            if (GCN) { acc.fma(wgt[u], r[u]); wacc += wgt[u]; } else acc.add(r[u]);
+                        }
+                    }
+                }
+            }
+            const int seglen = end - beg;
+            beg = end;
+            if (!col_ok) continue;
+            // ---- epilogue for (i,k)
+            V<VEC> v = acc;
+            // constant row added to every x row of hops >= 1: hopk_node_path_emb(pe_attr == 0), KPGIN.py:92-94
+            const bool biased = p.xbias != nullptr && k >= 1;
+            V<VEC> xb = V<VEC>::zero();
+            if (biased) { xb = V<VEC>::load(p.xbias + c0); v.fma(GCN ? wacc : (float)seglen, xb); }
+            if (GCN) {
+                const float di = p.dis[i * p.K_csr + k];
+                V<VEC> self = V<VEC>::load(xk + i * p.x_sn);
+                self.add(xb);
+                if (TAB != 0) self.add(V<VEC>::load(tab + 1 * D + c0));  // self-loop code 1 (KPGCN.py:87-89)
+                v.fma(di, self);                                          // last term of the edge list
+                for (int q = 0; q < VEC; ++q) v.v[q] *= di;
+            }
+            if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
+            if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
+            if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
+            if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
+            if (COMBINE) {
+                const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
+                for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
+            } else {
+                v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
+            }
+        }
+        if (COMBINE && col_ok) hsum.store(p.hout + i * (int64_t)D + c0);
+    }
+}
+
+struct BwdParams {
+    int N, K, D, K_csr, n_code0, n_codek, mode;
+    const int32_t* rowptr;
+    const int32_t* col;
+    const uint16_t* code;
+    const float* dis;
+    const float* g; int64_t g_sn, g_sk;
+    const float* eps;
+    float* gx; int64_t gx_sn, gx_sk;
+    float* gtable0;
+    float* gtablek;
+};
+
+// TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
+//      2 = straight global atomics (tables too large for LDS)
+template <int VEC, int G, bool GCN, int TAB>
+__global__ void __launch_bounds__(kBlock)
+agg_bwd_kernel(const BwdParams p) {
+    const int MODE = p.mode;
+    extern __shared__ __attribute__((aligned(16))) float lds_gt[];
+    const int D = p.D;
+    const int n0 = p.n_code0 * D, nk = p.n_codek * D;
+    if (TAB == 1) {
+        for (int t = threadIdx.x; t < n0 + nk; t += kBlock) lds_gt[t] = 0.f;
+        __syncthreads();
+    }
+    float* gt0 = TAB == 1 ? lds_gt : p.gtable0;
+    float* gtk = TAB == 1 ? lds_gt + n0 : p.gtablek;
+
+    constexpr int NODES = kBlock / G;
+    const int sg = threadIdx.x / G;
+    const int sl = threadIdx.x % G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sg_lane0 = lane - sl;
+    const int c0 = sl * VEC;
+    const bool col_ok = c0 < D;
+    const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
+    const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+
+    for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
+        const int64_t j = w.cur * NODES + sg;
+        if (j >= p.N) continue;
+        const int32_t* rp = p.rowptr + j * p.K_csr;
+        int beg = rp[0];
+        for (int k = 0; k < p.K; ++k) {
+            const int end = rp[k + 1];
+            const float* gk = p.g + (int64_t)k * p.g_sk + c0;
+            float* gt = k == 0 ? gt0 : gtk;
+            const float dj = GCN ? p.dis[j * p.K_csr + k] : 1.0f;
+            V<VEC> acc = V<VEC>::zero();
+            for (int base = beg; base < end; base += G) {
+                const int idx = base + sl;
+                int myi = 0, myc = 0;
+                if (idx < end) {
+                    myi = p.col[idx];
+                    if (TAB != 0) myc = p.code[idx];
+                }
+                float myw = 1.0f;
+                if (GCN && idx < end) myw = dj * p.dis[(int64_t)myi * p.K_csr + k];
+                const int cnt = min(G, end - base);
+                for (int t = 0; t < cnt; t += 4) {
+                    int ii[4], c[4]; float wgt[4]; V<VEC> r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
+                        ii[u] = __shfl(myi, srcl);
+                        if (TAB != 0) c[u] = __shfl(myc, srcl);
+                        if (GCN) wgt[u] = __shfl(myw, srcl);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        r[u] = V<VEC>::zero();
+                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(gk + (int64_t)ii[u] * p.g_sn);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (t + u < cnt && col_ok) {
+                            if (GCN) { for (int q = 0; q < VEC; ++q) r[u].v[q] *= wgt[u]; }
+                            acc.add(r[u]);
+                            if (TAB != 0) {
+                                float* dst = gt + c[u] * D + c0;
+                                for (int q = 0; q < VEC; ++q) atomicAdd(dst + q, r[u].v[q]);
+                            }
+                        }
+                    }
+                }
+            }
+            beg = end;
+            if (!col_ok) continue;
+            if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, V<VEC>::load(gk + j * p.g_sn));
+            if (GCN) {
+                V<VEC> self = V<VEC>::load(gk + j * p.g_sn);
+                for (int q = 0; q < VEC; ++q) self.v[q] *= dj * dj;
+                acc.add(self);
+                if (TAB != 0) {
+                    float* dst = gt + 1 * D + c0;
+                    for (int q = 0; q < VEC; ++q) atomicAdd(dst + q, self.v[q]);
+                }
+            }
+            acc.store(p.gx + j * p.gx_sn + (int64_t)k * p.gx_sk + c0);
+        }
+    }
+    if (TAB == 1) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n0; t += kBlock) { const float v = lds_gt[t]; if (v != 0.f) atomicAdd(p.gtable0 + t, v); }
+        for (int t = threadIdx.x; t < nk; t += kBlock) { const float v = lds_gt[n0 + t]; if (v != 0.f) atomicAdd(p.gtablek + t, v); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- dispatch
+struct Shape { int vec, g; };
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+bool aligned8(const void* p) { return ((uintptr_t)p & 7) == 0; }
+
+int pick_vec(int D, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> strides) {
+    int vec = 4;
+    if (D % 4 != 0) vec = (D % 2 == 0) ? 2 : 1;
+    for (const void* q : ptrs) {
+        if (!q) continue;
+        if (vec == 4 && !aligned16(q)) vec = aligned8(q) ? 2 : 1;
+        if (vec == 2 && !aligned8(q)) vec = 1;
+    }
+    for (int64_t s : strides) {
+        if (vec == 4 && s % 4 != 0) vec = (s % 2 == 0) ? 2 : 1;
+        if (vec == 2 && s % 2 != 0) vec = 1;
+    }
+    return vec;
+}
+
+int pick_group(int lanes_needed) {
+    int g = 4;
+    while (g < lanes_needed) g <<= 1;
+    return g;
+}
+
+unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
+    const int64_t cap = (int64_t)device_facts().cu_count * blocks_per_cu;
+    int64_t g = num_tiles < cap ? num_tiles : cap;
+    if (g >= kNumXcd) g = g / kNumXcd * kNumXcd;  // XcdTileWalk wants a multiple of 8
+    return (unsigned)(g > 0 ? g : 1);
+}
+
+template <int VEC, int G, bool GCN, int TAB>
+int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
+    const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
+    const unsigned grid = pick_grid(tiles, 8);
+    if (lds > 64 * 1024)
+        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)agg_fwd_kernel<VEC, G, GCN, TAB>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
+    KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
+    return KPGNN_OK;
+}
+
+template <int VEC, int G>
+int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
+    const bool gcn = p.mode == KPGNN_MODE_GCN;
+    switch (tab) {
+        case 0: return gcn ? launch_fwd<VEC, G, true, 0>(p, 0, s) : launch_fwd<VEC, G, false, 0>(p, 0, s);
+        case 1: return gcn ? launch_fwd<VEC, G, true, 1>(p, lds, s) : launch_fwd<VEC, G, false, 1>(p, lds, s);
+        default: return gcn ? launch_fwd<VEC, G, true, 2>(p, 0, s) : launch_fwd<VEC, G, false, 2>(p, 0, s);
+    }
+}
+
+template <int VEC, int G, bool GCN, int TAB>
+int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
+    const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
+    const unsigned grid = pick_grid(tiles, 4);
+    if (lds > 64 * 1024)
+        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
+    KPGNN_LAUNCH_CHECK("agg_bwd_kernel");
+    return KPGNN_OK;
+}
+
+template <int VEC, int G>
+int launch_bwd_mode(const BwdParams& p, int tab, size_t lds, hipStream_t s) {
+    const bool gcn = p.mode == KPGNN_MODE_GCN;
+    switch (tab) {
+        case 0: return gcn ? launch_bwd<VEC, G, true, 0>(p, 0, s) : launch_bwd<VEC, G, false, 0>(p, 0, s);
+        case 1: return gcn ? launch_bwd<VEC, G, true, 1>(p, lds, s) : launch_bwd<VEC, G, false, 1>(p, lds, s);
+        default: return gcn ? launch_bwd<VEC, G, true, 2>(p, 0, s) : launch_bwd<VEC, G, false, 2>(p, 0, s);
+    }
+}
+
+// (VEC, G) pairs instantiated: G in {4,8,16,32,64}, G*VEC >= D  (D <= 256 for VEC 4).
+#define KP_DISPATCH_SHAPE(CALL)                                                                    \
+    switch (vec * 100 + g) {                                                                       \
+        case 404: return CALL(4, 4); case 408: return CALL(4, 8); case 416: return CALL(4, 16);    \
+        case 432: return CALL(4, 32); case 464: return CALL(4, 64);                                \
+        case 204: return CALL(2, 4); case 208: return CALL(2, 8); case 216: return CALL(2, 16);    \
+        case 232: return CALL(2, 32); case 264: return CALL(2, 64);                                \
+        case 104: return CALL(1, 4); case 108: return CALL(1, 8); case 116: return CALL(1, 16);    \
+        case 132: return CALL(1, 32); case 164: return CALL(1, 64);                                \
+    }
+
+}  // namespace
+}  // namespace kpgnn
+
+using namespace kpgnn;
+
+extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr, "aggregate_fwd: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->D >= 1 && d->K_csr >= d->K, "aggregate_fwd: bad N=%d K=%d D=%d K_csr=%d",
+                  d->N, d->K, d->D, d->K_csr);
+    if ((int64_t)d->N * d->K_csr >= ((int64_t)1 << 31)) return fail(KPGNN_ELIMIT, "aggregate_fwd: N*K exceeds int32");
+    if (d->N == 0) return KPGNN_OK;
+    KPGNN_REQUIRE(d->rowptr && d->x, "aggregate_fwd: NULL rowptr/x");
+    KPGNN_REQUIRE(d->mode >= KPGNN_MODE_GIN && d->mode <= KPGNN_MODE_SUM, "aggregate_fwd: unknown mode %d", d->mode);
+    KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || d->dis, "aggregate_fwd: GCN mode needs dis");
+    const bool combine = d->theta != nullptr;
+    KPGNN_REQUIRE(combine ? d->hout != nullptr : d->out != nullptr, "aggregate_fwd: NULL output");
+    int tab = 0;
+    size_t lds = 0;
+    if (d->use_tables) {
+        KPGNN_REQUIRE(d->table0 && d->n_code0 >= 1 && (d->K == 1 || (d->tablek && d->n_codek >= 1)),
+                      "aggregate_fwd: missing embedding tables");
+        KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || (d->n_code0 >= 2 && (d->K == 1 || d->n_codek >= 2)),
+                      "aggregate_fwd: GCN needs code row 1 (self loop) in both tables");
+        lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));
+        tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
+    }
+    FwdParams p;
+    p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
+    p.mode = d->mode; p.combine = combine ? 1 : 0;
+    p.rowptr = d->rowptr; p.col = d->col; p.code = d->code; p.dis = d->dis;
+    p.x = d->x; p.x_sn = d->x_sn; p.x_sk = d->x_sk;
+    p.table0 = d->table0; p.tablek = d->tablek;
+    p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
+    p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
+    const int vec = pick_vec(d->D, {d->x, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias},
+                             {d->x_sn, d->x_sk, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
+                              d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
+    const int lanes = (d->D + vec - 1) / vec;
+    if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_fwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);
+    const int g = pick_group(lanes);
+    hipStream_t s = (hipStream_t)stream;
+#define KP_CALL(VEC_, G_) launch_fwd_mode<VEC_, G_>(p, tab, lds, s)
+    KP_DISPATCH_SHAPE(KP_CALL)
+#undef KP_CALL
+    return fail(KPGNN_EINVAL, "aggregate_fwd: no kernel for vec=%d g=%d", vec, g);
+}
+
+extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr, "aggregate_bwd: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->D >= 1 && d->K_csr >= d->K, "aggregate_bwd: bad N=%d K=%d D=%d K_csr=%d",
+                  d->N, d->K, d->D, d->K_csr);
+    if ((int64_t)d->N * d->K_csr >= ((int64_t)1 << 31)) return fail(KPGNN_ELIMIT, "aggregate_bwd: N*K exceeds int32");
+    if (d->N == 0) return KPGNN_OK;
+    KPGNN_REQUIRE(d->rowptr_src && d->g && d->gx, "aggregate_bwd: NULL rowptr/g/gx");
+    KPGNN_REQUIRE(d->mode >= KPGNN_MODE_GIN && d->mode <= KPGNN_MODE_SUM, "aggregate_bwd: unknown mode %d", d->mode);
+    KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || d->dis, "aggregate_bwd: GCN mode needs dis");
+    int tab = 0;
+    size_t lds = 0;
+    if (d->use_tables && d->gtable0) {
+        KPGNN_REQUIRE(d->n_code0 >= 1 && (d->K == 1 || (d->gtablek && d->n_codek >= 1)), "aggregate_bwd: missing table grads");
+        lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));
+        tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
+    }
+    BwdParams p;
+    p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
+    p.mode = d->mode;
+    p.rowptr = d->rowptr_src; p.col = d->col_src; p.code = d->code_src; p.dis = d->dis;
+    p.g = d->g; p.g_sn = d->g_sn; p.g_sk = d->g_sk; p.eps = d->eps;
+    p.gx = d->gx; p.gx_sn = d->gx_sn; p.gx_sk = d->gx_sk; p.gtable0 = d->gtable0; p.gtablek = d->gtablek;
+    const int vec = pick_vec(d->D, {d->g, d->gx}, {d->g_sn, d->g_sk, d->gx_sn, d->gx_sk});
+    const int lanes = (d->D + vec - 1) / vec;
+    if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_bwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);
+    const int g = pick_group(lanes);
+    hipStream_t s = (hipStream_t)stream;
+#define KP_CALL(VEC_, G_) launch_bwd_mode<VEC_, G_>(p, tab, lds, s)
+    KP_DISPATCH_SHAPE(KP_CALL)
+#undef KP_CALL
+    return fail(KPGNN_EINVAL, "aggregate_bwd: no kernel for vec=%d g=%d", vec, g);
+}

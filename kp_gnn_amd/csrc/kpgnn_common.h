@@ -1,0 +1,75 @@
+// Shared helpers for libkpgnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "kpgnn.h"
+
+namespace kpgnn {
+
+char* error_buffer();  // thread-local, 512 bytes (defined in csr_build.hip)
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define KPGNN_HIP_TRY(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ::kpgnn::fail(KPGNN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define KPGNN_LAUNCH_CHECK(name)                                                                          \
+    do {                                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                                \
+        if (e_ != hipSuccess)                                                                             \
+            return ::kpgnn::fail(KPGNN_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_));     \
+    } while (0)
+
+#define KPGNN_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return ::kpgnn::fail(KPGNN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
+
+struct DeviceFacts {
+    int cu_count = 256;
+    int lds_per_block = 160 * 1024;
+    bool valid = false;
+};
+const DeviceFacts& device_facts();
+
+// XCD-aware tile order.  Blocks b and b+8 share an XCD (own L2).  The tile range is cut into 8
+// contiguous slabs, one per XCD, and the blocks of one XCD walk their slab tile by tile, so that
+// the rows a slab's graphs gather stay inside one 4 MiB L2.  Placement only affects speed.
+struct XcdTileWalk {
+    int64_t cur, end, step;
+    __device__ XcdTileWalk(int64_t num_tiles) {
+        const int64_t b = blockIdx.x, g = gridDim.x;
+        if (g < kNumXcd || (g % kNumXcd) != 0) {  // plain grid-stride
+            cur = b; end = num_tiles; step = g;
+            return;
+        }
+        const int64_t xcd = b % kNumXcd, slot = b / kNumXcd, nslot = g / kNumXcd;
+        const int64_t per = (num_tiles + kNumXcd - 1) / kNumXcd;
+        const int64_t lo = xcd * per;
+        int64_t hi = lo + per;
+        if (hi > num_tiles) hi = num_tiles;
+        cur = lo + slot; end = hi; step = nslot;
+    }
+    __device__ bool valid() const { return cur < end; }
+    __device__ void next() { cur += step; }
+};
+
+}  // namespace kpgnn

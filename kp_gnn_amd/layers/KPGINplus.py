@@ -1,0 +1,50 @@
+"""KP-GIN+ convolution on the MI355X hot path.
+
+Drop-in for the reference's layers/KPGINplus.py `KPGINPlusConv` (:11-88): x is the [N,k,H] stack of
+the previous layers' states; same constructor, attributes and state_dict keys.  With the geometric
+combine the whole of  combine( gelu(S) + peripheral )  (:64-78, combine.py:43-46) is ONE HIP launch
+that writes [N,H] directly; only the Linear-BN-ReLU x2 MLP (:25-30) is left to library GEMMs."""
+import torch
+import torch.nn as nn
+
+from .._lib import MODE_GINPLUS
+from ..ops import khop_aggregate
+from ._base import EdgeCodeTables, KHopMessagePassing
+from .combine import GeometricCombine, make_combine
+
+
+class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
+    def __init__(self, input_size, output_size, K, num_hop1_edge=1, num_pe=1, combine="independent"):
+        super().__init__()
+        self.K = K
+        self.output_size = output_size
+        self.mlp = nn.Sequential(nn.Linear(input_size, output_size), nn.BatchNorm1d(output_size), nn.ReLU(),
+                                 nn.Linear(output_size, output_size), nn.BatchNorm1d(output_size), nn.ReLU())
+        self._make_tables(input_size, K, num_hop1_edge, num_pe)
+        if K > 1:
+            self.combine = make_combine(combine, K, output_size)  # raises for "independent" like the reference
+        else:
+            self.combine = torch.squeeze
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._reset_tables()
+        for m in self.mlp:
+            if hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        if self.K > 1:
+            self.combine.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
+        n = x.size(0)
+        csr, k_act = self._csr(edge_index, edge_attr, n)
+        x, xbias = self._path_encoding(x, pe_attr)
+        t0, tk = self._tables()
+        if isinstance(self.combine, GeometricCombine):
+            h = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
+                               theta=self.combine.theta(), xbias=xbias)                      # N,H
+        else:
+            xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
+                                xbias=xbias)                                                  # N,k,H
+            h = self.combine(xn)
+        return self.mlp(h)

@@ -1,0 +1,181 @@
+"""Autograd operators over the C ABI (include/kpgnn.h).  Host-side plumbing only: tensors in, pointers
+and strides out; every arithmetic step of the K-hop aggregation runs in the HIP kernels."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MODE_GCN, MODE_GIN, MODE_GINPLUS, MODE_SUM
+
+_SQRT1_2 = 0.7071067811865476
+_INV_SQRT_2PI = 0.3989422804014327
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _last_contig(t):
+    """[N,K,D] view with unit innermost stride (copy only if the caller handed something exotic)."""
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.KpgnnError("kp_gnn_amd ops need CUDA/HIP tensors: there is no CPU fallback "
+                                  "(the CPU restatement lives in oracle/ and is test-only)")
+
+
+def _check_codes(csr, k_act, table0, tablek):
+    if csr.A == 0:
+        return
+    if csr.max_code0 >= table0.shape[0]:
+        raise IndexError(f"edge code {csr.max_code0} out of range for hop1_edge_emb with {table0.shape[0]} rows")
+    if k_act > 1 and tablek is not None and csr.max_codek >= tablek.shape[0]:
+        raise IndexError(f"edge code {csr.max_codek} out of range for hopk_edge_emb with {tablek.shape[0]} rows")
+
+
+def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre):
+    """Launch kpgnn_aggregate_fwd.  Returns (out or hout, pre or None)."""
+    lib = _lib.load()
+    N, K, D = x.shape
+    assert K == k_act and N == csr.N
+    dev = x.device
+    d = _lib.AggFwdDesc()
+    d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
+    use_tables = table0 is not None
+    d.use_tables = 1 if use_tables else 0
+    d.n_code0 = table0.shape[0] if use_tables else 0
+    d.n_codek = tablek.shape[0] if (use_tables and tablek is not None) else 0
+    d.rowptr, d.col, d.code = csr.rowptr_dst.data_ptr(), csr.col_dst.data_ptr(), csr.code_dst.data_ptr()
+    d.dis = csr.gcn_dis().data_ptr() if mode == MODE_GCN else None
+    d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
+    d.table0, d.tablek = _ptr(table0), _ptr(tablek)
+    if periph is not None:
+        d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
+    d.eps = _ptr(eps)
+    d.xbias = _ptr(xbias)
+    pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
+    d.pre = _ptr(pre)
+    if theta is not None:
+        out = torch.empty((N, D), dtype=torch.float32, device=dev)
+        d.theta, d.hout = theta.data_ptr(), out.data_ptr()
+    else:
+        out = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+        d.out, d.o_sn, d.o_sk = out.data_ptr(), out.stride(0), out.stride(1)
+    with torch.cuda.device(dev):
+        _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(x)), "kpgnn_aggregate_fwd")
+    return out, pre
+
+
+def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
+    """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek)."""
+    lib = _lib.load()
+    N, K, D = g.shape
+    dev = g.device
+    d = _lib.AggBwdDesc()
+    d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
+    d.use_tables = 1 if want_tables else 0
+    d.n_code0, d.n_codek = n_code0, n_codek
+    d.rowptr_src, d.col_src, d.code_src = csr.rowptr_src.data_ptr(), csr.col_src.data_ptr(), csr.code_src.data_ptr()
+    d.dis = csr.gcn_dis().data_ptr() if mode == MODE_GCN else None
+    d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
+    d.eps = _ptr(eps)
+    gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
+    gt0 = gtk = None
+    if want_tables:
+        gt0 = torch.zeros((n_code0, D), dtype=torch.float32, device=dev)
+        d.gtable0 = gt0.data_ptr()
+        if K > 1 and n_codek > 0:
+            gtk = torch.zeros((n_codek, D), dtype=torch.float32, device=dev)
+            d.gtablek = gtk.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(lib.kpgnn_aggregate_bwd(ctypes.byref(d), _stream(g)), "kpgnn_aggregate_bwd")
+    return gx, gt0, gtk
+
+
+def _gelu_grad(pre):
+    # d/ds [0.5 s (1 + erf(s/sqrt2))] = Phi(s) + s phi(s)
+    return 0.5 * (1.0 + torch.erf(pre * _SQRT1_2)) + pre * torch.exp(-0.5 * pre * pre) * _INV_SQRT_2PI
+
+
+class KHopAggregate(torch.autograd.Function):
+    """out[N,k,D] (or hout[N,D] with a fused geometric combine) = epilogue(K-hop segmented sum).
+
+    Differentiable w.r.t. x, table0, tablek, periph, eps, theta.  `xbias` (a detached constant row, see
+    kpgnn.h) carries no gradient: it is the padding row of hopk_node_path_emb, whose grad the reference's
+    nn.Embedding(padding_idx=0) discards as well."""
+
+    @staticmethod
+    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, csr, k_act, mode):
+        _require_cuda(x, table0, tablek, periph, eps, theta, xbias)
+        x = _last_contig(x.float())
+        if periph is not None:
+            periph = _last_contig(periph.float())
+        if table0 is not None:
+            table0 = table0.contiguous()
+            tablek = tablek.contiguous() if tablek is not None else None
+            _check_codes(csr, k_act, table0, tablek)
+        if theta is not None:
+            theta = theta.contiguous()
+        need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
+        out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre)
+        ctx.csr, ctx.k_act, ctx.mode = csr, k_act, mode
+        ctx.has_tables = table0 is not None
+        ctx.n_code0 = table0.shape[0] if table0 is not None else 0
+        ctx.n_codek = tablek.shape[0] if tablek is not None else 0
+        ctx.has_periph = periph is not None
+        eps_needs = eps is not None and eps.requires_grad
+        ctx.save_for_backward(pre, eps, theta, periph if theta is not None else None,
+                              x if eps_needs else None, xbias if eps_needs else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pre, eps, theta, periph, x_saved, xbias = ctx.saved_tensors
+        mode = ctx.mode
+        gtheta = None
+        if theta is not None:
+            # hout = sum_k theta[k] * v[k],  v = act(S) + P
+            gout = gout.contiguous()
+            if mode == MODE_GINPLUS:
+                act = torch.nn.functional.gelu(pre)
+            elif mode == MODE_GCN:
+                act = torch.relu(pre)
+            else:
+                act = pre
+            v = act if periph is None else act + periph
+            gtheta = torch.einsum("nd,nkd->kd", gout, v)
+            gv = gout.unsqueeze(1) * theta.unsqueeze(0)
+        else:
+            gv = _last_contig(gout)
+        gperiph = gv if ctx.has_periph else None
+        if mode == MODE_GINPLUS:
+            g = gv * _gelu_grad(pre)
+        elif mode == MODE_GCN:
+            g = gv * (pre > 0).to(gv.dtype)
+        else:
+            g = gv
+        g = _last_contig(g)
+        want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        gx, gt0, gtk = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, want_tables)
+        geps = None
+        if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
+            xe = x_saved
+            if xbias is not None and xe.shape[1] > 1:
+                xe = torch.cat([xe[:, :1], xe[:, 1:] + xbias], dim=1)
+            geps = (g * xe).sum().reshape(eps.shape)
+        # (row 0 of both table grads stays exactly zero: code 0 == "inactive" never enters the CSR, which
+        #  is also what nn.Embedding(padding_idx=0) would do)
+        return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta,
+                None, None, None, None)
+
+
+def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None):
+    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, csr, k_act, mode)

@@ -1,0 +1,269 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (a) the golden vectors produced by the
+reference's own layer files and (b) the CPU oracle on seeded inputs.  fp32; tolerances written below."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4   # fp32 layer outputs / grads vs the reference CPU path
+ATOL = 1e-5   # times max(1, |ref|_max)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, b, name, rtol=RTOL, atol=ATOL):
+    a = a.detach().cpu()
+    b = b.detach().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol * scale), (name, float((a - b).abs().max()), scale)
+
+
+# ----------------------------------------------------------------------------- K-hop CSR (integer: bit-exact)
+def _csr_reference(edge_index, edge_attr, N):
+    """numpy restatement of the CSR contract in include/kpgnn.h (stable order inside a segment)."""
+    E, K = edge_attr.shape
+    e, k = np.nonzero(edge_attr)
+    out = {}
+    for name, owner, other in (("dst", edge_index[1], edge_index[0]), ("src", edge_index[0], edge_index[1])):
+        key = owner[e] * K + k
+        order = np.argsort(key, kind="stable")
+        rowptr = np.zeros(N * K + 1, dtype=np.int64)
+        np.add.at(rowptr, key + 1, 1)
+        out[name] = (np.cumsum(rowptr), other[e][order], edge_attr[e, k][order])
+    return out
+
+
+@pytest.mark.parametrize("N,E,K,density", [(50, 400, 8, 0.2), (7, 30, 1, 1.0), (1000, 20000, 16, 0.6), (5, 0, 3, 0.5),
+                                           (300, 5000, 4, 0.0)])
+def test_khop_csr_build_bit_exact(N, E, K, density):
+    from kp_gnn_amd.khop_csr import KHopCSR
+    rng = np.random.default_rng(N * 131 + E)
+    ei = rng.integers(0, N, size=(2, E))
+    ea = rng.integers(1, 60, size=(E, K)) * (rng.random((E, K)) < density)
+    csr = KHopCSR.build(torch.from_numpy(ei).to(_dev()), torch.from_numpy(ea).to(_dev()), N)
+    ref = _csr_reference(ei, ea, N)
+    assert csr.A == int((ea != 0).sum())
+    for name, (rp, col, code) in (("dst", (csr.rowptr_dst, csr.col_dst, csr.code_dst)),
+                                  ("src", (csr.rowptr_src, csr.col_src, csr.code_src))):
+        r_rp, r_col, r_code = ref[name]
+        assert np.array_equal(rp.cpu().numpy(), r_rp), name
+        assert np.array_equal(col.cpu().numpy()[:csr.A], r_col), name
+        assert np.array_equal(code.cpu().numpy()[:csr.A].astype(np.uint16), r_code.astype(np.uint16)), name
+
+
+def test_khop_csr_rejects_bad_input():
+    from kp_gnn_amd.khop_csr import KHopCSR
+    ei = torch.tensor([[0, 5], [1, 2]], device=_dev())
+    with pytest.raises(IndexError):
+        KHopCSR.build(ei, torch.ones(2, 2, dtype=torch.long, device=_dev()), 4)
+    with pytest.raises(ValueError):
+        KHopCSR.build(torch.tensor([[0, 1], [1, 2]], device=_dev()),
+                      torch.tensor([[1, -1], [0, 2]], device=_dev()), 4)
+
+
+def test_khop_csr_is_shared_across_prefix_views():
+    from kp_gnn_amd.khop_csr import get_khop_csr
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]], device=_dev())
+    ea = torch.tensor([[2, 0, 0], [0, 3, 0], [0, 0, 4]], device=_dev())
+    c1, k1 = get_khop_csr(ei, ea[:, :1], 3)
+    c2, k2 = get_khop_csr(ei, ea[:, :3], 3)
+    c3, k3 = get_khop_csr(ei, ea, 3)
+    assert c1 is c2 is c3 and (k1, k2, k3) == (1, 3, 3) and c1.K == 3
+    ea[0, 1] = 7  # in-place edit bumps the version -> rebuild
+    c4, _ = get_khop_csr(ei, ea, 3)
+    assert c4 is not c1 and c4.A == 4
+
+
+# ----------------------------------------------------------------------------- layers vs reference goldens
+def _make_layer(case):
+    from kp_gnn_amd import layers as L
+    ctor = dict(case["ctor"])
+    for b in ("train_eps",):
+        if b in ctor:
+            ctor[b] = bool(ctor[b])
+    cls = {"KPGIN": L.KPGINConv, "KPGINPlus": L.KPGINPlusConv, "KPGCN": L.KPGCNConv, "GINE": L.GINEConv}[case["kind"]]
+    layer = cls(**ctor)
+    missing = layer.load_state_dict(case["state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return layer.to(_dev()).train()
+
+
+def _layer_cases(golden_dir):
+    return torch.load(os.path.join(golden_dir, "layers.pt"), weights_only=True)
+
+
+def test_layers_match_reference_goldens(golden_dir):
+    cases = _layer_cases(golden_dir)
+    dev = _dev()
+    for name, case in cases.items():
+        layer = _make_layer(case)
+        x = case["x"].to(dev).requires_grad_(True)
+        x_before = x.detach().clone()
+        periph = case.get("peripheral_attr")
+        if periph is not None:
+            periph = periph.to(dev).requires_grad_(True)
+        pe = case.get("pe_attr")
+        pe = pe.to(dev) if pe is not None else None
+        ei, ea = case["edge_index"].to(dev), case["edge_attr"].to(dev)
+        if case["kind"] == "GINE":
+            out = layer(x, ei, ea)
+        else:
+            out = layer(x, ei, ea, pe, periph)
+        (out * case["out_weight"].to(dev)).sum().backward()
+        assert torch.equal(x.detach(), x_before), name + ": input mutated"
+        _close(out, case["out"], name + ":out")
+        _close(x.grad, case["grad_x"], name + ":grad_x")
+        if periph is not None:
+            _close(periph.grad, case["grad_peripheral_attr"], name + ":grad_periph")
+        gscale = max(float(g.abs().max()) for g in case["param_grads"].values())
+        params = dict(layer.named_parameters())
+        assert sorted(params) == sorted(case["param_grads"]), name
+        for k, g in case["param_grads"].items():
+            got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+            assert torch.allclose(got.cpu(), g, rtol=RTOL, atol=ATOL * max(1.0, gscale)), \
+                (name, k, float((got.cpu() - g).abs().max()), gscale)
+        sd = layer.state_dict()
+        for k, v in case["state_dict_after"].items():
+            if "running" in k:
+                _close(sd[k], v, f"{name}:{k}")
+
+
+# ----------------------------------------------------------------------------- raw aggregation vs the oracle
+def _random_khop(N, E, K, seed, n0=5, nk=12, density=0.3):
+    rng = np.random.default_rng(seed)
+    ei = rng.integers(0, N, size=(2, E))
+    ea = np.zeros((E, K), dtype=np.int64)
+    act = rng.random((E, K)) < density
+    ea[:, 0] = rng.integers(2, n0, size=E) * act[:, 0]
+    if K > 1:
+        ea[:, 1:] = rng.integers(2, nk, size=(E, K - 1)) * act[:, 1:]
+    return torch.from_numpy(ei), torch.from_numpy(ea)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 6, 13, 16, 20, 33, 40, 64, 104, 120, 256])
+@pytest.mark.parametrize("mode", ["gin", "ginplus", "gcn", "sum"])
+def test_aggregate_modes_and_widths_vs_oracle(D, mode):
+    """Every (VEC, sub-group) kernel shape and epilogue, fwd + bwd, against the materialised CPU sequence."""
+    from oracle import kp_layers_oracle as LO
+    from kp_gnn_amd import _lib
+    from kp_gnn_amd.khop_csr import KHopCSR
+    from kp_gnn_amd.ops import khop_aggregate
+    dev = _dev()
+    N, E, K = 61, 700, 5
+    ei, ea = _random_khop(N, E, K, seed=D)
+    g = torch.Generator().manual_seed(D * 7 + len(mode))
+    x = torch.randn(N, K, D, generator=g)
+    t0 = torch.randn(5, D, generator=g)
+    tk = torch.randn(12, D, generator=g)
+    t0[0] = 0
+    tk[0] = 0
+    P = torch.randn(N, K, D, generator=g)
+    eps = torch.tensor([0.3])
+    w = torch.randn(N, K, D, generator=g)
+
+    # --- oracle (CPU, materialised [E,K,D] messages)
+    xo, t0o, tko, Po = (t.clone().requires_grad_(True) for t in (x, t0, tk, P))
+    p = {"hop1_edge_emb.weight": t0o, "hopk_edge_emb.weight": tko}
+    if mode == "gcn":
+        loop = torch.arange(N)
+        ei2 = torch.cat([ei, loop.unsqueeze(0).repeat(2, 1)], 1)
+        ea2 = torch.cat([ea, torch.ones(N, K, dtype=torch.long)], 0)
+        emb = LO.edge_code_embedding(p, ea2, K)
+        deg = LO.khop_degree(ei2[1], N, ea2)
+        dis = deg.pow(-0.5)
+        norm = dis[ei2[0]] * dis[ei2[1]]
+        msg = (norm.unsqueeze(-1) * (xo.index_select(0, ei2[0]) + emb)).masked_fill(ea2.unsqueeze(-1) == 0, 0.)
+        ref = torch.relu(LO.propagate_sum(N, ei2, msg)) + Po
+    else:
+        emb = LO.edge_code_embedding(p, ea, K)
+        s = LO.propagate_sum(N, ei, LO.masked_message(xo.index_select(0, ei[0]), emb, ea))
+        ref = {"gin": lambda: s + Po + (1 + eps) * xo, "ginplus": lambda: torch.nn.functional.gelu(s) + Po,
+               "sum": lambda: s + Po}[mode]()
+    (ref * w).sum().backward()
+
+    # --- HIP
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    xd, t0d, tkd, Pd = (t.clone().to(dev).requires_grad_(True) for t in (x, t0, tk, P))
+    m = {"gin": _lib.MODE_GIN, "ginplus": _lib.MODE_GINPLUS, "gcn": _lib.MODE_GCN, "sum": _lib.MODE_SUM}[mode]
+    out = khop_aggregate(xd, csr, K, m, table0=t0d, tablek=tkd, periph=Pd, eps=eps.to(dev) if mode == "gin" else None)
+    (out * w.to(dev)).sum().backward()
+    _close(out, ref, "out")
+    _close(xd.grad, xo.grad, "grad_x")
+    _close(Pd.grad, Po.grad, "grad_P")
+    _close(t0d.grad, t0o.grad, "grad_table0", atol=3e-5)
+    _close(tkd.grad, tko.grad, "grad_tablek", atol=3e-5)
+
+
+def test_aggregate_strided_views_prefix_and_empty():
+    """x as a strided [N,k,H] view, hop-prefix of a wider CSR (GNNs.py:429), nodes with no edges, fused theta."""
+    from oracle import kp_layers_oracle as LO
+    from kp_gnn_amd import _lib
+    from kp_gnn_amd.khop_csr import get_khop_csr
+    from kp_gnn_amd.ops import khop_aggregate
+    dev = _dev()
+    N, E, K, k, D = 40, 300, 6, 3, 24
+    ei, ea = _random_khop(N, E, K, seed=5)
+    ei[:, :] = ei % (N - 5)  # last 5 nodes isolated
+    hist = torch.randn(N, 9, D)
+    x = hist[:, 2:2 + k]  # strided view, no copy
+    t0 = torch.randn(5, D)
+    tk = torch.randn(12, D)
+    theta = torch.softmax(torch.randn(k, D), 0)
+    P = torch.randn(N, K, D)[:, :k]
+    p = {"hop1_edge_emb.weight": t0, "hopk_edge_emb.weight": tk}
+    emb = LO.edge_code_embedding(p, ea[:, :k], k)
+    s = LO.propagate_sum(N, ei, LO.masked_message(x.index_select(0, ei[0]), emb, ea[:, :k]))
+    ref = ((torch.nn.functional.gelu(s) + P) * theta.unsqueeze(0)).sum(1)
+    ead = ea.to(dev)
+    csr, kk = get_khop_csr(ei.to(dev), ead[:, :k], N)
+    assert kk == k and csr.K == K
+    xd = hist.to(dev)[:, 2:2 + k]
+    assert not xd.is_contiguous()
+    out = khop_aggregate(xd, csr, k, _lib.MODE_GINPLUS, table0=t0.to(dev), tablek=tk.to(dev),
+                         periph=P.to(dev)[:, :k], theta=theta.to(dev))
+    _close(out, ref, "fused-combine prefix")
+
+
+def test_path_encoding_bias_row_is_honoured():
+    """A manually overwritten padding row of hopk_node_path_emb is added to x[:,1:] like the reference does."""
+    from oracle import kp_layers_oracle as LO
+    from kp_gnn_amd.layers import KPGINConv, KPGCNConv
+    dev = _dev()
+    N, E, K = 30, 200, 4
+    ei, ea = _random_khop(N, E, K, seed=11, n0=4, nk=8)
+    pe = torch.zeros(N, K - 1, dtype=torch.long)
+    for cls, fwd in ((KPGINConv, LO.kpgin_forward), (KPGCNConv, LO.kpgcn_forward)):
+        torch.manual_seed(3)
+        layer = cls(24, 24, K, num_hop1_edge=2, num_pe=8, combine="geometric")
+        with torch.no_grad():
+            layer.hopk_node_path_emb.weight[0] = torch.randn(6)
+        x = torch.randn(N, 24)
+        P = torch.randn(N, K, 6)
+        ref = fwd({k: v.clone() for k, v in layer.state_dict().items()}, x, ei, ea, pe, P, K=K, combine_kind="geometric")
+        out = layer.to(dev)(x.to(dev), ei.to(dev), ea.to(dev), pe.to(dev), P.to(dev))
+        _close(out, ref, cls.__name__)
+    # and the generic (non-zero pe_attr) path
+    pe2 = torch.randint(0, 8, (N, K - 1))
+    torch.manual_seed(4)
+    layer = KPGINConv(24, 24, K, num_hop1_edge=2, num_pe=8, combine="attention")
+    ref = LO.kpgin_forward({k: v.clone() for k, v in layer.state_dict().items()}, x, ei, ea, pe2, P, K=K,
+                           combine_kind="attention")
+    out = layer.to(dev)(x.to(dev), ei.to(dev), ea.to(dev), pe2.to(dev), P.to(dev))
+    _close(out, ref, "generic pe")
+
+
+def test_code_out_of_range_raises():
+    from kp_gnn_amd.layers import KPGINConv
+    dev = _dev()
+    layer = KPGINConv(8, 8, 2, num_hop1_edge=1, num_pe=3).to(dev)
+    ei = torch.tensor([[0, 1], [1, 0]], device=dev)
+    ea = torch.tensor([[2, 0], [0, 9]], device=dev)  # 9 >= num_pe + 2 rows
+    with pytest.raises(IndexError):
+        layer(torch.randn(2, 8, device=dev), ei, ea)
