@@ -1,0 +1,59 @@
+"""Collated K-hop batch: what PyG's DataLoader + the reference's pre_transform hand to the model
+(train_ZINC.py:209-224), as one plain attribute bag whose tensors live in HBM, with the K-hop CSR built
+once and attached so that no layer call pays for it."""
+import torch
+
+from . import khop_transform as KT
+from .khop_csr import KHopCSR, attach_khop_csr
+
+_TENSORS = ("x", "edge_index", "edge_attr", "pe_attr", "peripheral_edge_attr", "peripheral_configuration_attr",
+            "batch", "y")
+
+
+class KHopBatch:
+    def __init__(self, **kw):
+        self.num_graphs = kw.pop("num_graphs", None)
+        self.csr = None
+        for k in _TENSORS:
+            setattr(self, k, kw.get(k))
+
+    @property
+    def num_nodes(self):
+        return self.x.size(0)
+
+    def to(self, device):
+        out = KHopBatch(num_graphs=self.num_graphs)
+        for k in _TENSORS:
+            v = getattr(self, k)
+            setattr(out, k, None if v is None else v.to(device, non_blocking=True))
+        return out
+
+    def build_csr(self):
+        """Build the device CSR now and pin it to this batch's edge_index (layers pick it up)."""
+        self.csr = KHopCSR.build(self.edge_index, self.edge_attr, self.num_nodes)
+        attach_khop_csr(self.edge_index, self.edge_attr, self.num_nodes, self.csr)
+        return self.csr
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in _TENSORS if getattr(self, k) is not None}
+
+
+def collate_khop(node_ptr, edge_ptr, edge_index, edge_attr, x, khop_args, y=None, num_threads=0):
+    """Raw graphs (CSR-style concatenation, local node ids) -> exact K-hop pre-transform -> collated batch."""
+    out = KT.khop_batch(node_ptr, edge_ptr, edge_index, edge_attr, *khop_args, num_threads=num_threads)
+    xt = torch.as_tensor(x)
+    if xt.dim() == 1:
+        xt = xt.view(-1, 1)
+    return KHopBatch(x=xt, edge_index=out["edge_index"], edge_attr=out["edge_attr"], pe_attr=out["pe_attr"],
+                     peripheral_edge_attr=out["peripheral_edge_attr"],
+                     peripheral_configuration_attr=out["peripheral_configuration_attr"], batch=out["batch"], y=y,
+                     num_graphs=len(node_ptr) - 1)
+
+
+def synthetic_zinc_batch(num_graphs, seed0, K=8, kernel="spd", num_threads=0):
+    """ZINC-12k-shaped synthetic batch with the reference's ZINC pre-transform arguments
+    (train_ZINC.py:125-134,191-194: max_pe_num=50, max_hop_num=6, max_edge_type=3, counts 50)."""
+    node_ptr, edge_ptr, ei, ea, x = KT.synth_molecules(num_graphs, seed0)
+    g = torch.Generator().manual_seed(int(seed0))
+    y = torch.randn(num_graphs, generator=g)
+    return collate_khop(node_ptr, edge_ptr, ei, ea, x, (K, 50, 6, 3, 50, 50, kernel), y=y, num_threads=num_threads)

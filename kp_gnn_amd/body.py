@@ -1,0 +1,382 @@
+"""Caller side of the hot path: the GNN bodies and the graph-regression head that drive the K-hop layers.
+
+The reference's models/GNNs.py (GNN :22-235, GNNPlus :238-474, GNNPrime :478-722), models/
+GraphRegression.py:9-51 and the small encoders (layers/input_encoder.py:9-23, feature_encoder.py:37-67) are
+the *callers* of the path this package accelerates; with PyG installed they run unchanged on top of
+kp_gnn_amd.layers.  PyG is absent here and on the GPU box, so bench.py / smoke() / the body-level parity
+tests need a caller of their own: this file.  It keeps the reference's constructor arguments and
+state_dict key names (so reference checkpoints and the golden bodies load verbatim) but shares one base
+class instead of three near-identical copies, and only implements norm_type="Batch".
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers.gine import GINEConv
+
+
+# ------------------------------------------------------------------------------------------------ small pieces
+def _get(data, name):
+    try:
+        v = getattr(data, name)
+    except AttributeError:
+        return None
+    return v
+
+
+def global_add_pool(x, batch, size=None):
+    size = int(batch[-1].item()) + 1 if size is None else size
+    return x.new_zeros((size,) + tuple(x.shape[1:])).index_add_(0, batch, x)
+
+
+class EmbeddingEncoder(nn.Module):
+    """layers/input_encoder.py:9-23."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.init_proj = nn.Embedding(input_size, hidden_size)
+
+    def reset_parameters(self):
+        self.init_proj.reset_parameters()
+
+    def forward(self, data):
+        return self.init_proj(data.x)
+
+
+class LinearEncoder(nn.Module):
+    """layers/input_encoder.py:26-40."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.init_proj = nn.Linear(input_size, hidden_size)
+
+    def reset_parameters(self):
+        self.init_proj.reset_parameters()
+
+    def forward(self, data):
+        return self.init_proj(data.x)
+
+
+class FeatureConcatEncoder(nn.Module):
+    """Per-column embedding -> concat -> Linear (layers/feature_encoder.py:37-67)."""
+
+    def __init__(self, feature_dims, hidden_size, padding=False):
+        super().__init__()
+        self.embedding_list = nn.ModuleList(
+            nn.Embedding(d, hidden_size, padding_idx=0) if padding else nn.Embedding(d, hidden_size)
+            for d in feature_dims)
+        self.proj = nn.Linear(len(feature_dims) * hidden_size, hidden_size)
+
+    def reset_parameters(self):
+        for e in self.embedding_list:
+            e.reset_parameters()
+        self.proj.reset_parameters()
+
+    def forward(self, x):
+        cols = [emb(x[..., i]) for i, emb in enumerate(self.embedding_list)]
+        return self.proj(torch.cat(cols, dim=-1))
+
+
+class BatchNorm(nn.Module):
+    """PyG's BatchNorm wrapper: parameters live under `.module` (state_dict key compatibility)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels)
+
+    def reset_parameters(self):
+        self.module.reset_parameters()
+
+    def forward(self, x):
+        return self.module(x)
+
+
+def _vn_mlp(h):
+    return nn.Sequential(nn.Linear(h, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Linear(h, h), nn.BatchNorm1d(h), nn.ReLU())
+
+
+def _reset(m):
+    if hasattr(m, "reset_parameters"):
+        m.reset_parameters()
+
+
+# ------------------------------------------------------------------------------------------------ bodies
+class _KHopBody(nn.Module):
+    """Everything the three reference bodies have in common.  `width` is the per-hop width of the
+    peripheral features (dk for GNN / GNNPrime, H for GNNPlus); `gate` their squashing (Q11)."""
+
+    def __init__(self, num_layer, hidden_size, K, width, gate, init_emb, num_hop1_edge, max_edge_count, max_hop_num,
+                 max_distance_count, JK, norm_type, virtual_node, residual, use_rd, wo_peripheral_edge,
+                 wo_peripheral_configuration, drop_prob):
+        super().__init__()
+        self.num_layer, self.hidden_size, self.K = num_layer, hidden_size, K
+        self._periph_width, self._gate = width, gate
+        self.dropout = nn.Dropout(drop_prob)
+        self.JK, self.residual, self.use_rd, self.virtual_node = JK, residual, use_rd, virtual_node
+        self.wo_peripheral_edge = wo_peripheral_edge
+        self.wo_peripheral_configuration = wo_peripheral_configuration
+        jk_in = (num_layer + 1) * hidden_size if JK == "concat" else hidden_size
+        self.output_proj = nn.Sequential(nn.Linear(jk_in, hidden_size), nn.ReLU(), nn.Dropout(drop_prob))
+        if JK == "attention":
+            self.attention_lstm = nn.LSTM(hidden_size, num_layer, 1, batch_first=True, bidirectional=True, dropout=0.)
+        self.init_proj = init_emb
+        if use_rd:
+            self.rd_projection = nn.Linear(1, hidden_size)
+        if virtual_node:
+            self.virtualnode_embedding = nn.Embedding(1, hidden_size)
+            self.mlp_virtualnode_list = nn.ModuleList(_vn_mlp(hidden_size) for _ in range(num_layer - 1))
+        if not wo_peripheral_edge:
+            # the reference passes `padding=0` (GNNs.py:91), which is falsy: these tables have NO padding row
+            self.peripheral_edge_embedding = FeatureConcatEncoder([num_hop1_edge + 2, max_edge_count + 1], width,
+                                                                  padding=False)
+            self.pew = nn.Parameter(torch.rand(1))
+        if not wo_peripheral_configuration:
+            self.peripheral_configuration_embedding = FeatureConcatEncoder(
+                [max_distance_count + 1] * (max_hop_num + 1), width, padding=False)
+            self.pcw = nn.Parameter(torch.rand(1))
+        if norm_type != "Batch":
+            if norm_type in ("Layer", "Instance", "GraphSize", "Pair"):
+                raise NotImplementedError(f"norm_type={norm_type} is a PyG module; only 'Batch' is provided here")
+            raise ValueError("Not supported norm method")
+        self.norms = nn.ModuleList(BatchNorm(hidden_size) for _ in range(num_layer))
+
+    # -- parameter init shared by the three bodies (GNNs.py:122-140)
+    def _reset_common(self):
+        self.init_proj.reset_parameters()
+        if self.JK == "attention":
+            self.attention_lstm.reset_parameters()
+        self.output_proj.apply(_reset)
+        if self.use_rd:
+            self.rd_projection.reset_parameters()
+        if self.virtual_node:
+            nn.init.constant_(self.virtualnode_embedding.weight.data, 0)
+            self.mlp_virtualnode_list.apply(_reset)
+        if not self.wo_peripheral_edge:
+            self.peripheral_edge_embedding.reset_parameters()
+            nn.init.normal_(self.pew)
+        if not self.wo_peripheral_configuration:
+            self.peripheral_configuration_embedding.reset_parameters()
+            nn.init.normal_(self.pcw)
+
+    # -- pieces of forward
+    def _inputs(self, data):
+        x = self.init_proj(data).squeeze()
+        rd = _get(data, "rd")
+        if self.use_rd and rd is not None:
+            x = x + self.rd_projection(rd).squeeze()
+        return x
+
+    def _peripheral(self, data, num_nodes, like):
+        """GNNs.py:171-179 / :392-400 / :636-644."""
+        pea, pca = _get(data, "peripheral_edge_attr"), _get(data, "peripheral_configuration_attr")
+        out = None
+        if (not self.wo_peripheral_edge) and pea is not None:
+            out = self._gate(self.pew) * self.peripheral_edge_embedding(pea).sum(-2)
+        if (not self.wo_peripheral_configuration) and pca is not None:
+            t = self._gate(self.pcw) * self.peripheral_configuration_embedding(pca)
+            out = t if out is None else out + t
+        if out is None:
+            out = like.new_zeros(num_nodes, self.K, self._periph_width)
+        return out
+
+    def _vn_init(self, batch, edge_index):
+        idx = torch.zeros(int(batch[-1].item()) + 1, dtype=edge_index.dtype, device=edge_index.device)
+        return self.virtualnode_embedding(idx)
+
+    def _vn_update(self, l, vn, h_in, batch):
+        tmp = global_add_pool(h_in, batch, vn.size(0)) + vn
+        upd = self.dropout(self.mlp_virtualnode_list[l](tmp))
+        return vn + upd if self.residual else upd
+
+    def _jk(self, h_list):
+        if self.JK == "concat":
+            rep = torch.cat(h_list, dim=1)
+        elif self.JK == "last":
+            rep = h_list[-1]
+        elif self.JK == "max":
+            rep = torch.stack(h_list, dim=-1).max(dim=-1).values
+        elif self.JK == "sum":
+            rep = torch.stack(h_list, dim=0).sum(dim=0)
+        elif self.JK == "attention":
+            hs = torch.stack(h_list, dim=1)
+            self.attention_lstm.flatten_parameters()
+            score, _ = self.attention_lstm(hs)
+            rep = (hs * torch.softmax(score.sum(-1), dim=1).unsqueeze(-1)).sum(1)
+        else:
+            raise NameError(f"JK={self.JK} is not implemented (as in the reference, Q14)")
+        return self.output_proj(rep)
+
+
+class GNN(_KHopBody):
+    """Body for KPGCN / KPGIN layers (reference models/GNNs.py:22-235): one layer cloned num_layer times."""
+
+    def __init__(self, num_layer, gnn_layer, init_emb, num_hop1_edge, max_edge_count, max_hop_num, max_distance_count,
+                 JK="last", norm_type="batch", virtual_node=True, residual=False, use_rd=False,
+                 wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.1):
+        super().__init__(num_layer, gnn_layer.output_size, gnn_layer.K, gnn_layer.output_dk, torch.sigmoid, init_emb,
+                         num_hop1_edge, max_edge_count, max_hop_num, max_distance_count, JK, norm_type, virtual_node,
+                         residual, use_rd, wo_peripheral_edge, wo_peripheral_configuration, drop_prob)
+        self.output_dk = gnn_layer.output_dk
+        self.gnns = nn.ModuleList(copy.deepcopy(gnn_layer) for _ in range(num_layer))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._reset_common()
+        for g in self.gnns:
+            g.reset_parameters()
+
+    def forward(self, data):
+        edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
+        pe_attr = _get(data, "pe_attr")
+        x = self._inputs(data)
+        periph = self._peripheral(data, x.size(0), x)
+        vn = self._vn_init(batch, edge_index) if self.virtual_node else None
+        h_list = [x]
+        for l in range(self.num_layer):
+            if self.virtual_node:
+                h_list[l] = h_list[l] + vn[batch]
+            h = self.norms[l](self.gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph))
+            if l != self.num_layer - 1:
+                h = self.dropout(h)
+            if self.residual:
+                h = h + h_list[l]
+            h_list.append(h)
+            if self.virtual_node and l < self.num_layer - 1:
+                vn = self._vn_update(l, vn, h_list[l], batch)
+        return self._jk(h_list)
+
+
+class GNNPlus(_KHopBody):
+    """Body for KP-GIN+ (reference models/GNNs.py:238-474): layer l sees the last min(l+1,K) states as its
+    hop slots and the first k columns of edge_attr / peripheral features (:410-429)."""
+
+    def __init__(self, num_layer, gnn_layer, init_emb, num_hop1_edge, max_edge_count, max_hop_num, max_distance_count,
+                 JK="last", norm_type="batch", virtual_node=True, residual=False, use_rd=False,
+                 wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.1):
+        hidden, K = gnn_layer[-1].output_size, gnn_layer[-1].K
+        assert num_layer >= K
+        super().__init__(num_layer, hidden, K, hidden, torch.tanh, init_emb, num_hop1_edge, max_edge_count, max_hop_num,
+                         max_distance_count, JK, norm_type, virtual_node, residual, use_rd, wo_peripheral_edge,
+                         wo_peripheral_configuration, drop_prob)
+        self.gnns = nn.ModuleList(gnn_layer)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._reset_common()
+        for g in self.gnns:
+            g.reset_parameters()
+
+    def forward(self, data):
+        edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
+        pe_attr = _get(data, "pe_attr")
+        x = self._inputs(data)
+        periph = self._peripheral(data, x.size(0), x)
+        vn = self._vn_init(batch, edge_index) if self.virtual_node else None
+        h_list, last_h = [x], x
+        for l in range(self.num_layer):
+            if self.virtual_node:
+                h_list[l] = h_list[l] + vn[batch]
+            k = min(l + 1, self.K)
+            xs = torch.stack([h_list[l - m] for m in range(k)], dim=1)  # slot m = state of layer l-m
+            pek = pe_attr[:, :k - 1] if pe_attr is not None else None
+            h = self.gnns[l](xs, edge_index, edge_attr[:, :k], pek, periph[:, :k])
+            h = self.norms[l](h)
+            if l != self.num_layer - 1:
+                h = self.dropout(h)
+            if self.residual:
+                h = h + last_h
+                last_h = h
+            h_list.append(h)
+            if self.virtual_node and l < self.num_layer - 1:
+                vn = self._vn_update(l, vn, h_list[l], batch)
+        return self._jk(h_list)
+
+
+class GNNPrime(_KHopBody):
+    """Body for KP-GIN' (reference models/GNNs.py:478-722): num_l1_layer K-hop layers, then GINE layers that
+    walk the same K-hop edge list masked by its hop-1 column (:676-679)."""
+
+    def __init__(self, num_layer, gnn_layer, init_emb, num_hop1_edge, max_edge_count, max_hop_num, max_distance_count,
+                 num_l1_layer=1, JK="last", norm_type="batch", virtual_node=True, residual=False, use_rd=False,
+                 wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.1):
+        assert num_l1_layer > 0
+        assert num_layer >= 2
+        super().__init__(num_layer, gnn_layer.output_size, gnn_layer.K, gnn_layer.output_dk, torch.sigmoid, init_emb,
+                         num_hop1_edge, max_edge_count, max_hop_num, max_distance_count, JK, norm_type, virtual_node,
+                         residual, use_rd, wo_peripheral_edge, wo_peripheral_configuration, drop_prob)
+        self.output_dk = gnn_layer.output_dk
+        self.num_l1_layer, self.num_l2_layer = num_l1_layer, num_layer - num_l1_layer
+        self.khop_gnns = nn.ModuleList(copy.deepcopy(gnn_layer) for _ in range(num_l1_layer))
+        gine = GINEConv(self.hidden_size, self.hidden_size, num_hop1_edge=num_hop1_edge)
+        self.gins = nn.ModuleList(copy.deepcopy(gine) for _ in range(self.num_l2_layer))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._reset_common()
+        for g in list(self.khop_gnns) + list(self.gins):
+            g.reset_parameters()
+
+    def forward(self, data):
+        edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
+        pe_attr = _get(data, "pe_attr")
+        x = self._inputs(data)
+        periph = self._peripheral(data, x.size(0), x)
+        vn = self._vn_init(batch, edge_index) if self.virtual_node else None
+        h_list = [x]
+        for l in range(self.num_layer):
+            if self.virtual_node:
+                h_list[l] = h_list[l] + vn[batch]
+            if l < self.num_l1_layer:
+                h = self.khop_gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph)
+            else:
+                h = self.gins[l - self.num_l1_layer](h_list[l], edge_index, edge_attr[:, :1])
+            h = self.norms[l](h)
+            if l < self.num_l1_layer or l != self.num_layer - 1:  # (:659 drops out after every K-hop layer)
+                h = self.dropout(h)
+            if self.residual:
+                h = h + h_list[l]
+            h_list.append(h)
+            if self.virtual_node and l < self.num_layer - 1:
+                vn = self._vn_update(l, vn, h_list[l], batch)
+        return self._jk(h_list)
+
+
+def make_GNN(args):
+    """models/model_utils.py:8-14."""
+    return {"KPGINPlus": GNNPlus, "KPGINPrime": GNNPrime}.get(args.model_name, GNN)
+
+
+class GraphRegression(nn.Module):
+    """Pool + Linear head (reference models/GraphRegression.py:9-51); sum / mean / max pooling."""
+
+    def __init__(self, embedding_model, pooling_method):
+        super().__init__()
+        self.embedding_model = embedding_model
+        self.JK, self.num_layer = embedding_model.JK, embedding_model.num_layer
+        self.pooling_method = pooling_method
+        if pooling_method not in ("sum", "mean", "max"):
+            if pooling_method == "attention":
+                raise NotImplementedError("attention pooling is a PyG module")
+            raise ValueError("The pooling method not implemented")
+        self.regressor = nn.Linear(embedding_model.hidden_size, 1)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embedding_model.reset_parameters()
+        self.regressor.reset_parameters()
+
+    def pool(self, x, batch, num_graphs=None):
+        size = int(batch[-1].item()) + 1 if num_graphs is None else num_graphs
+        if self.pooling_method == "sum":
+            return global_add_pool(x, batch, size)
+        if self.pooling_method == "mean":
+            cnt = x.new_zeros(size).index_add_(0, batch, x.new_ones(batch.numel()))
+            return global_add_pool(x, batch, size) / cnt.clamp(min=1).unsqueeze(-1)
+        idx = batch.view(-1, 1).expand_as(x)
+        return x.new_full((size, x.size(1)), float("-inf")).scatter_reduce(0, idx, x, reduce="amax")
+
+    def forward(self, data):
+        x = self.embedding_model(data)
+        return self.regressor(self.pool(x, data.batch, _get(data, "num_graphs"))).squeeze()

@@ -267,3 +267,51 @@ def test_code_out_of_range_raises():
     ea = torch.tensor([[2, 0], [0, 9]], device=dev)  # 9 >= num_pe + 2 rows
     with pytest.raises(IndexError):
         layer(torch.randn(2, 8, device=dev), ei, ea)
+
+
+# ----------------------------------------------------------------------------- whole bodies vs reference goldens
+class _Batch:
+    def __init__(self, d, dev):
+        for k, v in d.items():
+            setattr(self, k, v.to(dev) if torch.is_tensor(v) else v)
+
+
+def _build_body(case):
+    import argparse
+    from kp_gnn_amd import body as B
+    from kp_gnn_amd.layers import make_gnn_layer
+    hp = case["hparams"]
+    args = argparse.Namespace(model_name=case["model_name"], hidden_size=case["h"], K=case["K"], num_layer=case["L"],
+                              num_hop1_edge=hp["num_hop1_edge"], max_pe_num=hp["max_pe_num"], combine=case["combine"],
+                              eps=0., train_eps=False, aggr="add")
+    gnn = B.make_GNN(args)(num_layer=case["L"], gnn_layer=make_gnn_layer(args), JK=case["JK"], norm_type="Batch",
+                           init_emb=B.EmbeddingEncoder(21, case["h"]), residual=bool(case["residual"]),
+                           virtual_node=bool(case["virtual_node"]), use_rd=False, num_hop1_edge=hp["num_hop1_edge"],
+                           max_edge_count=hp["max_edge_count"], max_hop_num=hp["max_hop_num"],
+                           max_distance_count=hp["max_distance_count"], wo_peripheral_edge=False,
+                           wo_peripheral_configuration=False, drop_prob=0.0)
+    model = B.GraphRegression(gnn, "sum")
+    res = model.load_state_dict(case["state_dict"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model
+
+
+def test_bodies_match_reference_goldens(golden_dir):
+    """GNN / GNNPlus / GNNPrime + GraphRegression, L1 loss, fwd+bwd: score, loss, every parameter grad."""
+    cases = torch.load(os.path.join(golden_dir, "bodies.pt"), weights_only=True)
+    dev = _dev()
+    for name, case in cases.items():
+        model = _build_body(case).to(dev).train()
+        data = _Batch(case["inputs"], dev)
+        score = model(data)
+        loss = (score.squeeze() - case["y"].to(dev).squeeze()).abs().mean()
+        loss.backward()
+        _close(score, case["score"], name + ":score", rtol=2e-4, atol=2e-5)
+        _close(loss, case["loss"], name + ":loss", rtol=2e-4, atol=2e-5)
+        gscale = max(float(g.abs().max()) for g in case["param_grads"].values())
+        params = dict(model.named_parameters())
+        assert sorted(params) == sorted(case["param_grads"]), name
+        for k, g in case["param_grads"].items():
+            got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+            assert torch.allclose(got.cpu(), g, rtol=2e-3, atol=5e-5 * max(1.0, gscale)), \
+                (name, k, float((got.cpu() - g).abs().max()), gscale)

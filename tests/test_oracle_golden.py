@@ -122,3 +122,30 @@ def test_path_encoding_table_never_trains(golden_dir):
         g = case["param_grads"].get("hopk_node_path_emb.weight")
         if g is not None:
             assert not g.any(), name
+
+
+# ----------------------------------------------------------------------------- whole bodies (fp32)
+BODY_KIND = {"KPGINPlus": ("GNNPlus", "KPGINPlus"), "KPGIN": ("GNN", "KPGIN"), "KPGCN": ("GNN", "KPGCN"),
+             "KPGINPrime": ("GNNPrime", "KPGIN")}
+
+
+def test_body_oracle_matches_reference(golden_dir):
+    from oracle import kp_model_oracle as MO
+    cases = torch.load(os.path.join(golden_dir, "bodies.pt"), weights_only=True)
+    assert len(cases) >= 6
+    for name, case in cases.items():
+        kind, layer_kind = BODY_KIND[case["model_name"]]
+        p = _leafify(case["state_dict"], case["param_grads"])
+        score = MO.graph_regression_forward(p, case["inputs"], kind=kind, layer_kind=layer_kind, K=case["K"],
+                                            num_layer=case["L"], combine_kind=case["combine"], JK=case["JK"],
+                                            residual=bool(case["residual"]), virtual_node=bool(case["virtual_node"]),
+                                            training=True)
+        loss = (score.squeeze() - case["y"].squeeze()).abs().mean()
+        loss.backward()
+        _close(score.detach(), case["score"], name + ":score", rtol=1e-4, atol=1e-5)
+        _close(loss.detach(), case["loss"], name + ":loss", rtol=1e-4, atol=1e-5)
+        gscale = max(float(g.abs().max()) for g in case["param_grads"].values())
+        for k, g in case["param_grads"].items():
+            got = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+            assert torch.allclose(got, g, rtol=1e-3, atol=2e-5 * max(1.0, gscale)), \
+                (name, k, float((got - g).abs().max()), gscale)
