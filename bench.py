@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py - graphs/s of the KP-GIN+ training step (fwd + bwd + Adam) on ZINC-12k-shaped synthetic batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model KPGINPlus|KPGIN] [--combine geometric|attention]
+
+Workload (BASELINE.json configs[1], reference README.md:127 `train_ZINC.py --residual --K=8 --model_name=KPGINPlus
+--num_layer=8 --hidden_size=104`): GNNPlus body, K=8, L=8, h=104, geometric combine, JK=concat, BatchNorm, sum
+pooling, L1 loss, Adam; synthetic molecule graphs of ZINC-12k's shape (kpgnn_host.h, ~23 nodes / ~500 K=8-spd
+edges per graph), exact K-hop pre-transform by libkpgnn_host.so, random-init weights (seed 0).
+A "step" is one optimisation step on one pre-staged batch of B graphs per GPU (inputs and the K-hop CSR
+resident in HBM before the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
+ranks, model replicated, one RCCL all-reduce (mean) of the flat gradient bucket per step; weak scaling.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     HIP-event timing of the aggregation kernel launches inside the timed region vs the
+                  algorithmic bytes of SURVEY.md 8(d) (HBM bound, peak 8 TB/s);
+  "cpu_baseline": the oracle ("port": oracle/kp_model_oracle.py, the reference's materialised [E,K,D] op
+                  sequence in plain PyTorch) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def build_model(args, device):
+    from kp_gnn_amd import body as B
+    from kp_gnn_amd.layers import make_gnn_layer
+    ns = argparse.Namespace(model_name=args.model, hidden_size=args.hidden, K=args.K, num_layer=args.layers,
+                            num_hop1_edge=3, max_pe_num=50, combine=args.combine, eps=0., train_eps=False, aggr="add")
+    torch.manual_seed(0)
+    gnn = B.make_GNN(ns)(num_layer=args.layers, gnn_layer=make_gnn_layer(ns), JK="concat", norm_type="Batch",
+                         init_emb=B.EmbeddingEncoder(21, args.hidden), residual=True, virtual_node=False, use_rd=False,
+                         num_hop1_edge=3, max_edge_count=50, max_hop_num=6, max_distance_count=50,
+                         wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.0)
+    model = B.GraphRegression(gnn, "sum")
+    return model.to(device).train()
+
+
+def flatten_grads(model):
+    """Make every .grad a view of ONE flat fp32 bucket, so the data-parallel step is a single all-reduce."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
+def train_step(model, batch, opt, flat_grad, world):
+    flat_grad.zero_()
+    score = model(batch)
+    loss = (score.squeeze() - batch.y.squeeze()).abs().mean()  # train_ZINC.py:42
+    loss.backward()
+    if world > 1:
+        torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.AVG)
+    opt.step()
+    return loss
+
+
+def cpu_baseline(args, state_dict, threads):
+    """Oracle (CPU restatement of the reference path) fwd+bwd on a bounded sample of the same workload."""
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    from oracle import kp_model_oracle as MO
+    torch.set_num_threads(threads)
+    nb = args.cpu_graphs
+    b = synthetic_zinc_batch(nb, seed0=10_000_000, K=args.K)
+    data = b.as_dict()
+    kind, layer_kind = {"KPGINPlus": ("GNNPlus", "KPGINPlus"), "KPGIN": ("GNN", "KPGIN")}[args.model]
+    p = {}
+    for k, v in state_dict.items():
+        v = v.detach().cpu().clone()
+        p[k] = v.requires_grad_(True) if (v.is_floating_point() and "running" not in k and not k.endswith(".eps")) else v
+    times = []
+    for it in range(1 + args.cpu_iters):
+        for v in p.values():
+            if v.requires_grad:
+                v.grad = None
+        t0 = time.perf_counter()
+        score = MO.graph_regression_forward(p, data, kind=kind, layer_kind=layer_kind, K=args.K, num_layer=args.layers,
+                                            combine_kind=args.combine, JK="concat", residual=True, training=True)
+        loss = (score.squeeze() - data["y"].squeeze()).abs().mean()
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(nb / med, 2), "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"{nb} graphs x {args.cpu_iters} fwd+bwd iterations (median), oracle/kp_model_oracle.py, "
+                      f"torch {torch.__version__} CPU, no optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2048, help="graphs per GPU per step")
+    ap.add_argument("--num-batches", type=int, default=4, help="distinct pre-staged batches cycled through")
+    ap.add_argument("--model", default="KPGINPlus", choices=("KPGINPlus", "KPGIN"))
+    ap.add_argument("--combine", default="geometric", choices=("geometric", "attention"))
+    ap.add_argument("--K", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=104)
+    ap.add_argument("--cpu-graphs", type=int, default=128)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+
+    t_data = time.perf_counter()
+    batches = []
+    for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
+        seed0 = (rank * args.num_batches + i) * args.batch
+        b = synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K).to(device)
+        b.build_csr()
+        batches.append(b)
+    torch.cuda.synchronize()
+    t_data = time.perf_counter() - t_data
+
+    model = build_model(args, device)
+    flat_grad = flatten_grads(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    if world > 1:  # identical replicas
+        for p in list(model.parameters()) + list(model.buffers()):
+            torch.distributed.broadcast(p.data, 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        train_step(model, batches[i % len(batches)], opt, flat_grad, world)
+    timer = None
+    if not args.no_roofline:
+        timer = ops.LaunchTimer()
+        ops.set_launch_timer(timer)
+        train_step(model, batches[0], opt, flat_grad, world)  # primes the byte-accounting caches (untimed)
+        timer.records.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(model, batches[i % len(batches)], opt, flat_grad, world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_launch_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        total_graphs = args.batch * world * args.steps
+        b0 = batches[0]
+        out = {
+            "metric": "graphs/sec KP-GIN fwd+bwd, ZINC-12k K=8 L=8 h=104",
+            "value": round(total_graphs / elapsed, 1),
+            "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ZINC-12k-shaped synthetic molecules, {args.model} K={args.K} L={args.layers} "
+                                   f"h={args.hidden} {args.combine} combine, fwd+bwd+Adam, L1 loss",
+                       "graphs_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
+                       "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.edge_index.shape[1]),
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 5),
+                       "data_build_s": round(t_data, 2)},
+        }
+        if timer is not None:
+            s = timer.summary()
+            f = s.get("agg_fwd")
+            if f:
+                out["roofline"] = {"bound": "hbm", "kernel": "agg_fwd_kernel", "achieved": round(f["gbps"], 1),
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(f["gbps"] / HBM_PEAK_GBPS, 4),
+                                   "traffic": None, "launches": f["launches"], "avg_launch_ms": round(f["avg_ms"], 4),
+                                   "algorithmic_bytes_per_launch": int(f["bytes_per_launch"])}
+            g = s.get("agg_bwd")
+            if g:
+                out["roofline_bwd"] = {"bound": "hbm", "kernel": "agg_bwd_kernel", "achieved": round(g["gbps"], 1),
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(g["gbps"] / HBM_PEAK_GBPS, 4),
+                                       "launches": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4),
+                                       "algorithmic_bytes_per_launch": int(g["bytes_per_launch"])}
+        if world == 1 and not args.no_cpu_baseline:
+            sd = {k: v for k, v in model.state_dict().items()}
+            out["cpu_baseline"] = cpu_baseline(args, sd, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,10 +22,22 @@ class KHopCSR:
     """int32 CSR by (dst,hop) and by (src,hop) of the active (edge,hop) pairs."""
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
-                 "max_code0", "max_codek", "_dis", "device")
+                 "max_code0", "max_codek", "_dis", "_apairs", "device")
 
     def __init__(self):
         self._dis = None
+        self._apairs = {}
+
+    def active_pairs(self, k_active):
+        """Number of active (edge,hop) pairs within the first k_active hops (== A for k_active == K).
+        Used for byte accounting only; one host sync per distinct k, cached."""
+        if k_active >= self.K:
+            return self.A
+        if k_active not in self._apairs:
+            rp = self.rowptr_dst[:-1].view(self.N, self.K)
+            self._apairs[k_active] = int((self.rowptr_dst[k_active::self.K][:self.N] - rp[:, 0]).sum().item()) \
+                if self.N > 0 else 0
+        return self._apairs[k_active]
 
     def gcn_dis(self):
         """deg^-1/2 per (node,hop) with the KP-GCN self loop counted (layers/KPGCN.py:11-25,106-108)."""

@@ -15,6 +15,44 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class LaunchTimer:
+    """Opt-in per-launch timing of the aggregation kernels with HIP events recorded on the stream the
+    kernel is launched on (bench.py's roofline leg).  Each record: (kind, algorithmic_bytes, start, stop)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        """kind -> dict(launches, avg_ms, bytes_per_launch, gbps); call after a device synchronize."""
+        out = {}
+        for kind, nbytes, a, b in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "bytes": 0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["bytes"] += nbytes
+        for d in out.values():
+            d["avg_ms"] = d["ms"] / d["launches"]
+            d["bytes_per_launch"] = d["bytes"] / d["launches"]
+            d["gbps"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        return out
+
+
+_timer = None
+
+
+def set_launch_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def algorithmic_bytes(csr, k_act, D, n_tensors, n_rows_tables, extra_nd=0):
+    """s*N*k*D per streamed [N,k,D] tensor + (4+2) B per active pair + int32 row pointers
+    + the tables once (+ s*N*D per [N,D] tensor), s = 4 (fp32)."""
+    A = csr.active_pairs(k_act)
+    return 4 * csr.N * k_act * D * n_tensors + A * 6 + 4 * (csr.N * csr.K + 1) + 4 * D * n_rows_tables \
+        + 4 * csr.N * D * extra_nd
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -69,7 +107,15 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         out = torch.empty((N, K, D), dtype=torch.float32, device=dev)
         d.out, d.o_sn, d.o_sk = out.data_ptr(), out.stride(0), out.stride(1)
     with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(x)), "kpgnn_aggregate_fwd")
+        if _timer is not None:
+            e1.record()
+            n_t = 1 + (periph is not None) + (pre is not None) + (theta is None)  # x, P, pre, out
+            _timer.records.append(("agg_fwd", algorithmic_bytes(csr, K, D, n_t, d.n_code0 + d.n_codek,
+                                                                extra_nd=1 if theta is not None else 0), e0, e1))
     return out, pre
 
 
@@ -96,7 +142,14 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
             gtk = torch.zeros((n_codek, D), dtype=torch.float32, device=dev)
             d.gtablek = gtk.data_ptr()
     with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.kpgnn_aggregate_bwd(ctypes.byref(d), _stream(g)), "kpgnn_aggregate_bwd")
+        if _timer is not None:
+            e1.record()
+            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 2, (n_code0 + n_codek) if want_tables else 0),
+                                   e0, e1))
     return gx, gt0, gtk
 
 
