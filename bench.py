@@ -29,6 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+from kp_gnn_amd._env import usable_cpus  # noqa: E402
 
 
 def build_model(args, device):
@@ -91,6 +99,7 @@ def cpu_baseline(args, state_dict, threads):
         loss = (score.squeeze() - data["y"].squeeze()).abs().mean()
         loss.backward()
         dt = time.perf_counter() - t0
+        log(f"  cpu iter {it}: {dt:.2f}s")
         if it > 0:
             times.append(dt)
     times.sort()
@@ -137,15 +146,22 @@ def main():
     from kp_gnn_amd import ops
     from kp_gnn_amd.batch import synthetic_zinc_batch
 
+    threads = max(1, usable_cpus() // max(1, min(world, 8)))
+    torch.set_num_threads(threads)
+    if rank == 0:
+        log(f"world={world} host threads/rank={threads} (os.cpu_count={os.cpu_count()})")
     t_data = time.perf_counter()
     batches = []
     for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
         seed0 = (rank * args.num_batches + i) * args.batch
-        b = synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K).to(device)
+        b = synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K, num_threads=threads).to(device)
         b.build_csr()
         batches.append(b)
     torch.cuda.synchronize()
     t_data = time.perf_counter() - t_data
+    if rank == 0:
+        log(f"{args.num_batches} batches x {args.batch} graphs built + CSR on device in {t_data:.1f}s "
+            f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]})")
 
     model = build_model(args, device)
     flat_grad = flatten_grads(model)
@@ -162,6 +178,9 @@ def main():
 
     for i in range(args.warmup):
         train_step(model, batches[i % len(batches)], opt, flat_grad, world)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"{args.warmup} warm-up steps done")
     timer = None
     if not args.no_roofline:
         timer = ops.LaunchTimer()
@@ -180,6 +199,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    if rank == 0:
+        log(f"timed {args.steps} steps in {elapsed:.3f}s")
 
     if rank == 0:
         total_graphs = args.batch * world * args.steps
@@ -215,7 +236,8 @@ def main():
                                        "algorithmic_bytes_per_launch": int(g["bytes_per_launch"])}
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v for k, v in model.state_dict().items()}
-            out["cpu_baseline"] = cpu_baseline(args, sd, os.cpu_count() or 1)
+            log(f"cpu baseline: oracle on {threads} host threads, {args.cpu_graphs} graphs ...")
+            out["cpu_baseline"] = cpu_baseline(args, sd, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -141,6 +141,31 @@ typedef struct kpgnn_agg_bwd_desc {
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-table gather-sum: out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :].
+ * This is the reference's peripheral feature build (models/GNNs.py:172-179 / :393-400 / :637-644 via
+ * FeatureConcatEncoder, layers/feature_encoder.py:62-67): Linear(cat_c Emb_c[idx_c]) equals a sum of rows
+ * of the PROJECTED tables Emb_c @ W_c^T, so the [N,K,T,2H] concat, the Linear over it and the (sort-based)
+ * embedding backward disappear.  m runs over (node,hop), C = 2*max_edge_type + max_hop_num + 1 columns.
+ * The caller validates idx against the table sizes.  Tables are staged in LDS (column-split when large).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_tgs_desc {
+    int64_t M;                  /* rows */
+    int32_t C, D, R;            /* index columns, feature width, total table rows */
+    const uint16_t* idx;        /* device [M, C] */
+    const int32_t* col_offset;  /* device [C]: first row of column c's table inside `table` */
+    const float* table;         /* device [R, D] contiguous (forward) */
+    const float* bias;          /* device [D] or NULL (forward) */
+    float* out;                 /* device [M, D], row stride out_stride (forward) */
+    int64_t out_stride;
+    const float* gout;          /* device [M, D], row stride gout_stride (backward) */
+    int64_t gout_stride;
+    float* gtable;              /* device [R, D] contiguous, accumulated into with fp32 atomics (backward) */
+} kpgnn_tgs_desc;
+
+int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
+int kpgnn_table_gather_sum_bwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

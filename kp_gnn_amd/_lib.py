@@ -41,6 +41,14 @@ class AggBwdDesc(ctypes.Structure):
     ]
 
 
+class TgsDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
+        ("idx", c_vp), ("col_offset", c_vp), ("table", c_vp), ("bias", c_vp),
+        ("out", c_vp), ("out_stride", c_i64), ("gout", c_vp), ("gout_stride", c_i64), ("gtable", c_vp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/kpgnn.h declares
 SIGNATURES = {
     "kpgnn_abi_version": (ctypes.c_int, []),
@@ -52,6 +60,8 @@ SIGNATURES = {
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
+    "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
+    "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }
 
 _lib = None

@@ -15,6 +15,48 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
+from .ops import table_gather_sum
+
+_PIDX = "_kpgnn_packed_peripheral"
+
+
+def _packed_peripheral_index(pea, pca, sizes):
+    """[N,K,T,2] / [N,K,Hc] int64 -> ([N*K, C] uint16 rows, [C] int32 table offsets), cached on the source
+    tensor.  Column order: (type_t, count_t) for t < T, then the Hc configuration columns; `sizes` lists
+    the table heights in the order the tables are concatenated (type, count, conf_0..conf_Hc-1)."""
+    anchor = pea if pea is not None else pca
+    key = (None if pea is None else pea._version, None if pca is None else (id(pca), pca._version), tuple(sizes))
+    rec = getattr(anchor, _PIDX, None)
+    if rec is not None and rec[0] == key:
+        return rec[1], rec[2]
+    cols, table_of_col = [], []
+    starts = [0]
+    for n in sizes:
+        starts.append(starts[-1] + n)
+    ti = 0
+    if pea is not None:
+        N, K, T, two = pea.shape
+        cols.append(pea.reshape(N * K, T * 2))
+        table_of_col += [0, 1] * T
+        ti = 2
+    if pca is not None:
+        N, K, Hc = pca.shape
+        cols.append(pca.reshape(N * K, Hc))
+        table_of_col += list(range(ti, ti + Hc))
+    idx64 = torch.cat(cols, dim=1)
+    limit = torch.tensor([sizes[t] for t in table_of_col], device=idx64.device)
+    if idx64.numel() and bool(((idx64 < 0) | (idx64 >= limit)).any().item()):  # one sync per batch object
+        raise IndexError("peripheral attribute index out of range for its embedding table")
+    if max(sizes) > 65536:
+        raise ValueError("peripheral embedding table too large for uint16 indices")
+    idx = idx64.to(torch.int16) if max(sizes) <= 32768 else (idx64 - 65536 * (idx64 >= 32768)).to(torch.int16)
+    col_offset = torch.tensor([starts[t] for t in table_of_col], dtype=torch.int32, device=idx64.device)
+    idx = idx.contiguous()
+    try:
+        setattr(anchor, _PIDX, (key, idx, col_offset))
+    except Exception:  # pragma: no cover
+        pass
+    return idx, col_offset
 
 
 # ------------------------------------------------------------------------------------------------ small pieces
@@ -169,17 +211,34 @@ class _KHopBody(nn.Module):
         return x
 
     def _peripheral(self, data, num_nodes, like):
-        """GNNs.py:171-179 / :392-400 / :636-644."""
+        """Peripheral-subgraph features P [N,K,width] (GNNs.py:171-179 / :392-400 / :636-644).
+
+        Linear(cat_c Emb_c[i_c]) == sum_c (Emb_c W_c^T)[i_c] + b, so P is ONE multi-table gather-sum over
+        the projected (tiny) tables, gates and biases folded in (ops.table_gather_sum).  The int64 index
+        tensors are packed to uint16 once per batch object."""
         pea, pca = _get(data, "peripheral_edge_attr"), _get(data, "peripheral_configuration_attr")
-        out = None
-        if (not self.wo_peripheral_edge) and pea is not None:
-            out = self._gate(self.pew) * self.peripheral_edge_embedding(pea).sum(-2)
-        if (not self.wo_peripheral_configuration) and pca is not None:
-            t = self._gate(self.pcw) * self.peripheral_configuration_embedding(pca)
-            out = t if out is None else out + t
-        if out is None:
-            out = like.new_zeros(num_nodes, self.K, self._periph_width)
-        return out
+        use_e = (not self.wo_peripheral_edge) and pea is not None
+        use_c = (not self.wo_peripheral_configuration) and pca is not None
+        if not (use_e or use_c):
+            return like.new_zeros(num_nodes, self.K, self._periph_width)
+        W = self._periph_width
+        tables, sizes, bias = [], [], 0
+        if use_e:
+            enc, g = self.peripheral_edge_embedding, self._gate(self.pew)
+            T = pea.shape[-2]
+            for c, emb in enumerate(enc.embedding_list):
+                tables.append(g * (emb.weight @ enc.proj.weight[:, c * W:(c + 1) * W].t()))
+                sizes.append(emb.num_embeddings)
+            bias = bias + g * T * enc.proj.bias
+        if use_c:
+            enc, g = self.peripheral_configuration_embedding, self._gate(self.pcw)
+            for c, emb in enumerate(enc.embedding_list):
+                tables.append(g * (emb.weight @ enc.proj.weight[:, c * W:(c + 1) * W].t()))
+                sizes.append(emb.num_embeddings)
+            bias = bias + g * enc.proj.bias
+        idx, col_offset = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
+        out = table_gather_sum(torch.cat(tables, dim=0), bias, idx, col_offset)
+        return out.view(num_nodes, -1, W)
 
     def _vn_init(self, batch, edge_index):
         idx = torch.zeros(int(batch[-1].item()) + 1, dtype=edge_index.dtype, device=edge_index.device)

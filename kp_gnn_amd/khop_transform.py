@@ -8,6 +8,7 @@ import os
 import numpy as np
 import torch
 
+from ._env import usable_cpus
 from ._lib import KpgnnError
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -88,6 +89,8 @@ def khop_batch(node_ptr, edge_ptr, edge_index, edge_attr, K, max_edge_attr_num, 
         raise ValueError(f"unknown kernel {kernel!r}")
     args = KhopArgs(K, max_edge_attr_num, max_hop_num, max_edge_type, max_edge_count, max_distance_count,
                     0 if kernel == "spd" else 1)
+    if num_threads <= 0:
+        num_threads = usable_cpus()
     plan = ctypes.c_void_p()
     _check(lib.kpgnn_khop_plan_create(G, _p(node_ptr), _p(edge_ptr), _p(edge_index), _p(ea), ctypes.byref(args),
                                       num_threads, ctypes.byref(plan)), "kpgnn_khop_plan_create")

@@ -232,3 +232,49 @@ class KHopAggregate(torch.autograd.Function):
 
 def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None):
     return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, csr, k_act, mode)
+
+
+# ------------------------------------------------------------------------------------------------ table gather-sum
+class TableGatherSum(torch.autograd.Function):
+    """out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :]  (kpgnn_table_gather_sum_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, table, bias, idx, col_offset):
+        _require_cuda(table, bias, idx, col_offset)
+        lib = _lib.load()
+        table = table.contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        M, C = idx.shape
+        R, D = table.shape
+        out = torch.empty((M, D), dtype=torch.float32, device=table.device)
+        d = _lib.TgsDesc()
+        d.M, d.C, d.D, d.R = M, C, D, R
+        d.idx, d.col_offset, d.table, d.bias = idx.data_ptr(), col_offset.data_ptr(), table.data_ptr(), _ptr(bias)
+        d.out, d.out_stride = out.data_ptr(), out.stride(0)
+        with torch.cuda.device(table.device):
+            _lib.check(lib.kpgnn_table_gather_sum_fwd(ctypes.byref(d), _stream(table)), "kpgnn_table_gather_sum_fwd")
+        ctx.save_for_backward(idx, col_offset)
+        ctx.shape = (R, D)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, col_offset = ctx.saved_tensors
+        lib = _lib.load()
+        gout = _last_contig(gout)
+        R, D = ctx.shape
+        M, C = idx.shape
+        gtable = torch.zeros((R, D), dtype=torch.float32, device=gout.device)
+        d = _lib.TgsDesc()
+        d.M, d.C, d.D, d.R = M, C, D, R
+        d.idx, d.col_offset = idx.data_ptr(), col_offset.data_ptr()
+        d.gout, d.gout_stride, d.gtable = gout.data_ptr(), gout.stride(0), gtable.data_ptr()
+        with torch.cuda.device(gout.device):
+            _lib.check(lib.kpgnn_table_gather_sum_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_table_gather_sum_bwd")
+        gbias = gout.sum(0) if ctx.has_bias else None
+        return gtable, gbias, None, None
+
+
+def table_gather_sum(table, bias, idx, col_offset):
+    return TableGatherSum.apply(table, bias, idx, col_offset)

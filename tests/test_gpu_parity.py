@@ -315,3 +315,30 @@ def test_bodies_match_reference_goldens(golden_dir):
             got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
             assert torch.allclose(got.cpu(), g, rtol=2e-3, atol=5e-5 * max(1.0, gscale)), \
                 (name, k, float((got.cpu() - g).abs().max()), gscale)
+
+
+# ----------------------------------------------------------------------------- multi-table gather-sum
+@pytest.mark.parametrize("D,R_sizes", [(104, [5, 51] + [51] * 7), (13, [5, 51] + [51] * 7), (6, [3, 4]), (96, [6, 1001, 30])])
+def test_table_gather_sum_vs_torch(D, R_sizes):
+    """Peripheral feature build: fwd + table/bias grads vs plain embedding sums (LDS-staged, column-split)."""
+    from kp_gnn_amd.ops import table_gather_sum
+    dev = _dev()
+    g = torch.Generator().manual_seed(D)
+    C = len(R_sizes) + 2  # the first two tables are used twice (type/count of several edge types)
+    tab_of_col = [0, 1] + list(range(len(R_sizes)))
+    starts = np.concatenate([[0], np.cumsum(R_sizes)])
+    M = 777
+    idx = torch.stack([torch.randint(0, R_sizes[t], (M,), generator=g) for t in tab_of_col], 1)
+    table = torch.randn(int(starts[-1]), D, generator=g)
+    bias = torch.randn(D, generator=g)
+    w = torch.randn(M, D, generator=g)
+    off = torch.tensor([starts[t] for t in tab_of_col])
+    tr, br = table.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = br + tr[(idx + off).reshape(-1)].view(M, C, D).sum(1)
+    (ref * w).sum().backward()
+    td, bd = table.clone().to(dev).requires_grad_(True), bias.clone().to(dev).requires_grad_(True)
+    out = table_gather_sum(td, bd, idx.to(torch.int16).to(dev), off.to(torch.int32).to(dev))
+    (out * w.to(dev)).sum().backward()
+    _close(out, ref, "out")
+    _close(td.grad, tr.grad, "gtable", atol=3e-5)
+    _close(bd.grad, br.grad, "gbias", atol=3e-5)
