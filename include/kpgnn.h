@@ -66,11 +66,16 @@ size_t kpgnn_csr_workspace_bytes(int64_t E, int64_t A, int64_t N, int32_t K);
  *   rowptr_dst int32[N*K+1], col_dst int32[A] (= source node), code_dst uint16[A]   -- keyed by (dst,hop)
  *   rowptr_src int32[N*K+1], col_src int32[A] (= dest node),   code_src uint16[A]   -- keyed by (src,hop)
  * Entries of one segment keep the order of the input edge list (stable), which is the reference's CPU
- * summation order (index_add_ over edges in order). */
+ * summation order (index_add_ over edges in order).
+ * Optional third ordering for kpgnn_table_grad (tile_ptr == NULL skips it): the active pairs sorted by
+ * (destination tile, table, code), tile = dst / nodes_per_tile (1..8):
+ *   tile_ptr int32[ceil(N/nodes_per_tile)+1], tile_pack uint32[A] = table<<31 | code<<15 | node_in_tile<<12 | hop
+ *   (table 0 = hop 0 -> hop1_edge_emb, table 1 = hops >= 1 -> hopk_edge_emb; codes < 2^16, hops < 2^12). */
 int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t* edge_attr, int64_t attr_stride,
                     int64_t E, int32_t K, int64_t N, int64_t A,
                     int32_t* rowptr_dst, int32_t* col_dst, uint16_t* code_dst,
                     int32_t* rowptr_src, int32_t* col_src, uint16_t* code_src,
+                    int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                     void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -140,6 +145,26 @@ typedef struct kpgnn_agg_bwd_desc {
 } kpgnn_agg_bwd_desc;
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
+
+/* Edge-code table gradients WITHOUT per-edge atomics:
+ *   gtable_t[c,:] += sum over active pairs (i,k) of table t with code c of g[i,k,:]      (g = dL/dS)
+ * (the reference gets them from nn.Embedding's backward of the materialised [E,K,D] embedding tensor,
+ * KPGIN.py:90-96).  A block streams tiles of `nodes_per_tile` destination nodes of g through LDS; thread t
+ * owns feature column t, walks the tile's (table,code)-sorted pair list and keeps the running sum of the
+ * current code in a register, so the LDS accumulators are column-private (no atomics); one fp32 global
+ * atomic per table element per block at the end.  K here is the number of ACTIVE hops of g (pairs with
+ * hop >= K are skipped). */
+typedef struct kpgnn_table_grad_desc {
+    int32_t N, K, D, nodes_per_tile, n_code0, n_codek;
+    const int32_t* tile_ptr;
+    const uint32_t* tile_pack;
+    const float* g;             /* device [N,K,D] */
+    int64_t g_sn, g_sk;
+    float* gtable0;             /* device [n_code0, D], accumulated into (caller zeroes) */
+    float* gtablek;             /* device [n_codek, D] or NULL when K == 1 */
+} kpgnn_table_grad_desc;
+
+int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-table gather-sum: out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :].

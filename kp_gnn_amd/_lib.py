@@ -41,6 +41,15 @@ class AggBwdDesc(ctypes.Structure):
     ]
 
 
+class TableGradDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("nodes_per_tile", c_i32), ("n_code0", c_i32), ("n_codek", c_i32),
+        ("tile_ptr", c_vp), ("tile_pack", c_vp),
+        ("g", c_vp), ("g_sn", c_i64), ("g_sk", c_i64),
+        ("gtable0", c_vp), ("gtablek", c_vp),
+    ]
+
+
 class TgsDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
@@ -57,9 +66,11 @@ SIGNATURES = {
     "kpgnn_csr_stats": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "kpgnn_csr_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i64, c_i64, c_i32]),
     "kpgnn_csr_build": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_i64,
-                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                       c_vp, ctypes.c_size_t, c_vp]),
     "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
+    "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

@@ -135,6 +135,43 @@ rowptr_unpack_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restri
     }
 }
 
+// Third ordering, for the table-gradient kernel: active pairs sorted by (destination tile, table, code).
+// tile = dst / nodes_per_tile.  key = tile<<17 | class<<16 | code ; payload = class<<31 | code<<15 |
+// node_in_tile<<12 | hop  (class 0: hop 0 -> hop1_edge_emb, class 1: hops >= 1 -> hopk_edge_emb).
+__global__ void __launch_bounds__(kThreads)
+expand_tile_pairs_kernel(const int64_t* __restrict__ ei, int64_t ei_stride, const int64_t* __restrict__ attr,
+                         int64_t attr_stride, int64_t E, int K, int nodes_per_tile,
+                         const int32_t* __restrict__ offs, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t dst = ei[ei_stride + e];
+    const uint64_t tile = (uint64_t)(dst / nodes_per_tile);
+    const uint32_t nit = (uint32_t)(dst % nodes_per_tile);
+    const int64_t* row = attr + e * attr_stride;
+    int32_t pos = offs[e];
+    for (int k = 0; k < K; ++k) {
+        const uint32_t v = (uint32_t)(row[k] & 0xFFFF);
+        if (row[k] != 0) {
+            const uint32_t cls = k == 0 ? 0u : 1u;
+            keys[pos] = (tile << 17) | ((uint64_t)cls << 16) | v;
+            vals[pos] = (cls << 31) | (v << 15) | (nit << 12) | (uint32_t)k;
+            ++pos;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+tile_ptr_kernel(const uint64_t* __restrict__ keys, int64_t A, int64_t num_tiles, int32_t* __restrict__ tptr) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t > num_tiles) return;
+    int64_t lo = 0, hi = A;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> 17) < t) lo = mid + 1; else hi = mid;
+    }
+    tptr[t] = (int32_t)lo;
+}
+
 struct Workspace {
     int32_t* offs;
     uint32_t *keys_a, *keys_b;
@@ -158,6 +195,11 @@ hipError_t plan_workspace(int64_t E, int64_t A, int64_t S, char* base, Workspace
     e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr,
                                   (uint64_t*)nullptr, (size_t)(A > 0 ? A : 1), 0, sort_bits(S));
     if (e != hipSuccess) return e;
+    size_t sort64_bytes = 0;
+    e = rocprim::radix_sort_pairs(nullptr, sort64_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, (size_t)(A > 0 ? A : 1), 0, 64);
+    if (e != hipSuccess) return e;
+    if (sort64_bytes > sort_bytes) sort_bytes = sort64_bytes;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     const size_t a = (size_t)(A > 0 ? A : 1);
@@ -223,6 +265,7 @@ extern "C" int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, con
                                int64_t attr_stride, int64_t E, int32_t K, int64_t N, int64_t A,
                                int32_t* rowptr_dst, int32_t* col_dst, uint16_t* code_dst,
                                int32_t* rowptr_src, int32_t* col_src, uint16_t* code_src,
+                               int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                                void* workspace, size_t workspace_bytes, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(E >= 0 && N >= 0 && A >= 0 && K >= 1, "csr_build: bad sizes E=%lld N=%lld A=%lld K=%d",
                   (long long)E, (long long)N, (long long)A, K);
@@ -236,9 +279,13 @@ extern "C" int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, con
     KPGNN_REQUIRE(E == 0 || (edge_index && edge_attr && ei_stride >= E && attr_stride >= K),
                   "csr_build: bad edge_index/edge_attr pointers or strides");
     hipStream_t s = (hipStream_t)stream;
+    KPGNN_REQUIRE(tile_ptr == nullptr || (nodes_per_tile >= 1 && nodes_per_tile <= 8 && K <= 4096 && (A == 0 || tile_pack)),
+                  "csr_build: tile list needs 1 <= nodes_per_tile <= 8, K <= 4096 and tile_pack");
+    const int64_t num_tiles = tile_ptr ? (N + nodes_per_tile - 1) / nodes_per_tile : 0;
     if (A == 0) {
         KPGNN_HIP_TRY(hipMemsetAsync(rowptr_dst, 0, sizeof(int32_t) * (size_t)(S + 1), s));
         KPGNN_HIP_TRY(hipMemsetAsync(rowptr_src, 0, sizeof(int32_t) * (size_t)(S + 1), s));
+        if (tile_ptr) KPGNN_HIP_TRY(hipMemsetAsync(tile_ptr, 0, sizeof(int32_t) * (size_t)(num_tiles + 1), s));
         return KPGNN_OK;
     }
     Workspace w;
@@ -267,6 +314,20 @@ extern "C" int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, con
                            orientation == 0 ? rowptr_dst : rowptr_src, orientation == 0 ? col_dst : col_src,
                            orientation == 0 ? code_dst : code_src);
         KPGNN_LAUNCH_CHECK("rowptr_unpack_kernel");
+    }
+    if (tile_ptr) {  // (tile, table, code)-sorted pair list; the u64/u32 buffers swap roles
+        uint64_t* k64a = w.vals_a; uint64_t* k64b = w.vals_b;
+        uint32_t* v32a = w.keys_a;
+        hipLaunchKernelGGL(expand_tile_pairs_kernel, dim3(eblocks), dim3(kThreads), 0, s, edge_index, ei_stride,
+                           edge_attr, attr_stride, E, (int)K, (int)nodes_per_tile, w.offs, k64a, v32a);
+        KPGNN_LAUNCH_CHECK("expand_tile_pairs_kernel");
+        int tbits = 17 + sort_bits(num_tiles + 1);
+        if (tbits > 64) tbits = 64;
+        tb = w.prim_bytes;
+        KPGNN_HIP_TRY(rocprim::radix_sort_pairs(w.prim_temp, tb, k64a, k64b, v32a, tile_pack, (size_t)A, 0, tbits, s));
+        const unsigned tblocks = (unsigned)((num_tiles + 1 + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(tile_ptr_kernel, dim3(tblocks), dim3(kThreads), 0, s, k64b, A, num_tiles, tile_ptr);
+        KPGNN_LAUNCH_CHECK("tile_ptr_kernel");
     }
     return KPGNN_OK;
 }

@@ -22,7 +22,9 @@ class KHopCSR:
     """int32 CSR by (dst,hop) and by (src,hop) of the active (edge,hop) pairs."""
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
-                 "max_code0", "max_codek", "_dis", "_apairs", "device")
+                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs", "device")
+
+    NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
 
     def __init__(self):
         self._dis = None
@@ -45,10 +47,6 @@ class KHopCSR:
             deg = (self.rowptr_dst[1:] - self.rowptr_dst[:-1] + 1).to(torch.float32)
             self._dis = deg.pow(-0.5).contiguous()
         return self._dis
-
-    def index_bytes(self, k_active=None):
-        """Algorithmic index bytes one aggregation launch streams: col(4)+code(2) per active pair + rowptr."""
-        return int(self.A) * 6 + 4 * (self.N * self.K + 1)
 
     @staticmethod
     def build(edge_index, edge_attr, num_nodes):
@@ -91,11 +89,16 @@ class KHopCSR:
             c.col_src = torch.empty(max(c.A, 1), **i32)
             c.code_dst = torch.empty(max(c.A, 1), dtype=torch.int16, device=dev)  # uint16 payload
             c.code_src = torch.empty(max(c.A, 1), dtype=torch.int16, device=dev)
+            c.nodes_per_tile = KHopCSR.NODES_PER_TILE
+            ntiles = (N + c.nodes_per_tile - 1) // c.nodes_per_tile
+            c.tile_ptr = torch.empty(ntiles + 1, **i32)
+            c.tile_pack = torch.empty(max(c.A, 1), **i32)  # uint32 payload
             ws_bytes = lib.kpgnn_csr_workspace_bytes(E, c.A, N, K)
             ws = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.kpgnn_csr_build(edge_index.data_ptr(), ei_stride, edge_attr.data_ptr(), at_stride, E, K, N,
                                            c.A, c.rowptr_dst.data_ptr(), c.col_dst.data_ptr(), c.code_dst.data_ptr(),
                                            c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr(),
+                                           c.nodes_per_tile, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(),
                                            ws.data_ptr(), ctypes.c_size_t(ws.numel()), stream), "kpgnn_csr_build")
         return c
 

@@ -153,6 +153,30 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
     return gx, gt0, gtk
 
 
+def table_grad_raw(csr, g, n_code0, n_codek):
+    """Launch kpgnn_table_grad: edge-code table gradients of g = dL/dS [N,k,D] (no per-edge atomics)."""
+    lib = _lib.load()
+    N, K, D = g.shape
+    dev = g.device
+    d = _lib.TableGradDesc()
+    d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, n_codek
+    d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
+    d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
+    gt0 = torch.zeros((n_code0, D), dtype=torch.float32, device=dev)
+    gtk = torch.zeros((n_codek, D), dtype=torch.float32, device=dev) if (K > 1 and n_codek > 0) else None
+    d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(g)), "kpgnn_table_grad")
+        if _timer is not None:
+            e1.record()
+            _timer.records.append(("table_grad", 4 * N * K * D + 4 * csr.active_pairs(K) + 4 * D * (n_code0 + n_codek),
+                                   e0, e1))
+    return gt0, gtk
+
+
 def _gelu_grad(pre):
     # d/ds [0.5 s (1 + erf(s/sqrt2))] = Phi(s) + s phi(s)
     return 0.5 * (1.0 + torch.erf(pre * _SQRT1_2)) + pre * torch.exp(-0.5 * pre * pre) * _INV_SQRT_2PI
@@ -217,7 +241,13 @@ class KHopAggregate(torch.autograd.Function):
             g = gv
         g = _last_contig(g)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        gx, gt0, gtk = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, want_tables)
+        gt0 = gtk = None
+        if want_tables and mode != MODE_GCN:
+            # table grads by the column-private streaming kernel; the gather then runs without atomics
+            gt0, gtk = table_grad_raw(ctx.csr, g, ctx.n_code0, ctx.n_codek)
+            gx, _, _ = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, False)
+        else:  # GCN weights its table grads per edge (dis[src]*dis[dst]): fused path
+            gx, gt0, gtk = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, want_tables)
         geps = None
         if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
             xe = x_saved

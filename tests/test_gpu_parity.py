@@ -342,3 +342,27 @@ def test_table_gather_sum_vs_torch(D, R_sizes):
     _close(out, ref, "out")
     _close(td.grad, tr.grad, "gtable", atol=3e-5)
     _close(bd.grad, br.grad, "gbias", atol=3e-5)
+
+
+def test_tile_sorted_pair_list_is_a_permutation_of_the_csr():
+    """The third CSR ordering (tile, table, code): same multiset of (dst, hop, code) as the by-destination CSR."""
+    from kp_gnn_amd.khop_csr import KHopCSR
+    N, E, K = 203, 3000, 6
+    ei, ea = _random_khop(N, E, K, seed=21)
+    csr = KHopCSR.build(ei.to(_dev()), ea.to(_dev()), N)
+    pack = csr.tile_pack.cpu().numpy().astype(np.uint32)[:csr.A]
+    tptr = csr.tile_ptr.cpu().numpy()
+    NT = csr.nodes_per_tile
+    assert tptr[0] == 0 and tptr[-1] == csr.A and (np.diff(tptr) >= 0).all()
+    tile_of = np.repeat(np.arange(len(tptr) - 1), np.diff(tptr))
+    hop = pack & 0xFFF
+    node = tile_of * NT + ((pack >> 12) & 7)
+    code = (pack >> 15) & 0xFFFF
+    table = pack >> 31
+    assert ((hop == 0) == (table == 0)).all()
+    got = sorted(zip(node.tolist(), hop.tolist(), code.tolist()))
+    e, k = np.nonzero(ea.numpy())
+    want = sorted(zip(ei.numpy()[1][e].tolist(), k.tolist(), ea.numpy()[e, k].tolist()))
+    assert got == want
+    key = (tile_of.astype(np.int64) << 17) | (table.astype(np.int64) << 16) | code
+    assert (np.diff(key) >= 0).all()
