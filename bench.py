@@ -228,6 +228,8 @@ def main():
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(f["gbps"] / HBM_PEAK_GBPS, 4),
                                    "traffic": None, "launches": f["launches"], "avg_launch_ms": round(f["avg_ms"], 4),
                                    "algorithmic_bytes_per_launch": int(f["bytes_per_launch"])}
+            out["kernels"] = {k: {"launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
+                                  "algorithmic_GBps": round(v["gbps"], 1)} for k, v in s.items()}
             g = s.get("agg_bwd")
             if g:
                 out["roofline_bwd"] = {"bound": "hbm", "kernel": "agg_bwd_kernel", "achieved": round(g["gbps"], 1),

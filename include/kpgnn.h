@@ -120,6 +120,13 @@ typedef struct kpgnn_agg_fwd_desc {
      * `x[:, 1:] += hopk_node_path_emb(pe_attr)` (KPGIN.py:92-94) when pe_attr is all padding (always so for
      * the reference's own pre-transform, data_utils.py:91,123): xbias = that table's row 0.  device [D]. */
     const float* xbias;
+    /* Optional DICTIONARY form of the peripheral features (used when periph == NULL): P[i,k,:] =
+     * ptab[uid[i*uid_stride + k], :].  Peripheral-subgraph feature tuples repeat massively (25 distinct
+     * rows among 379,600 (node,hop) slots of a 2048-molecule batch), so the [N,K,D] stream becomes an
+     * L2-resident table.  ptab: device [U, D] contiguous; uid: device int32. */
+    const float* ptab;
+    const int32_t* uid;
+    int64_t uid_stride;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
@@ -146,25 +153,67 @@ typedef struct kpgnn_agg_bwd_desc {
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
 
-/* Edge-code table gradients WITHOUT per-edge atomics:
- *   gtable_t[c,:] += sum over active pairs (i,k) of table t with code c of g[i,k,:]      (g = dL/dS)
+/* Table gradients WITHOUT per-edge atomics:
+ *   gtable_t[c,:] = sum over active pairs (i,k) of table t with code c of g[i,k,:]      (g = dL/dS)
  * (the reference gets them from nn.Embedding's backward of the materialised [E,K,D] embedding tensor,
- * KPGIN.py:90-96).  A block streams tiles of `nodes_per_tile` destination nodes of g through LDS; thread t
- * owns feature column t, walks the tile's (table,code)-sorted pair list and keeps the running sum of the
- * current code in a register, so the LDS accumulators are column-private (no atomics); one fp32 global
- * atomic per table element per block at the end.  K here is the number of ACTIVE hops of g (pairs with
- * hop >= K are skipped). */
+ * KPGIN.py:90-96), and optionally the gradient of a peripheral-feature DICTIONARY (see kpgnn_agg_fwd_desc.ptab):
+ *   gdict[u,:] = sum over (i,k) with uid[i,k] == u of  theta[k,:]*gh[i,:]   (dict_src 1, fused combine)
+ *                                                  or  g[i,k,:]             (dict_src 2, g is dL/dP itself)
+ * A block streams tiles of `nodes_per_tile` destination nodes of g through LDS; thread t owns feature column
+ * t, walks the tile's (table,code)-sorted pair list and keeps the running sum of the current code in a
+ * register, so the LDS accumulators are column-private (no atomics).  Per-block partial tables go to
+ * `workspace`; a second launch adds them in block order: outputs are OVERWRITTEN and bitwise reproducible.
+ * K is the number of ACTIVE hops of g (pairs with hop >= K are skipped).  tile_ptr == NULL skips the
+ * edge-code part (dictionary gradient only; gtable0/gtablek may then be NULL). */
 typedef struct kpgnn_table_grad_desc {
     int32_t N, K, D, nodes_per_tile, n_code0, n_codek;
+    int32_t n_dict, dict_src;   /* dictionary rows (0: none) and source (1: theta*gh, 2: g rows) */
     const int32_t* tile_ptr;
     const uint32_t* tile_pack;
     const float* g;             /* device [N,K,D] */
     int64_t g_sn, g_sk;
-    float* gtable0;             /* device [n_code0, D], accumulated into (caller zeroes) */
+    const int32_t* uid;         /* device [N, uid_stride]: dictionary row of (node, hop) */
+    int64_t uid_stride;
+    const float* theta;         /* device [K, D]  (dict_src 1) */
+    const float* gh;            /* device [N, D]  (dict_src 1) */
+    float* gtable0;             /* device [n_code0, D] */
     float* gtablek;             /* device [n_codek, D] or NULL when K == 1 */
+    float* gdict;               /* device [n_dict, D] */
+    void* workspace;            /* device, >= kpgnn_table_grad_workspace_bytes(...) */
+    size_t workspace_bytes;
 } kpgnn_table_grad_desc;
 
+size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
+                                        int32_t n_code0, int32_t n_codek, int32_t n_dict);
 int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream);
+
+/* Backward pre-pass of the fused epilogue (elementwise, streaming):  with v = act(S) + P,
+ *   gv[i,k,:] = theta[k,:] * gh[i,:]     (fused geometric combine)   or   gout[i,k,:]   (theta == NULL)
+ *   g[i,k,:]  = gv * act'(S[i,k,:])                      act = gelu (GINPLUS) / relu (GCN) / identity
+ *   gtheta[k,:] = sum_i gh[i,:] * v[i,k,:]               (only with theta)
+ * Replaces a dozen framework elementwise kernels (broadcast mul, erf, exp, mul, add, einsum ...) by one pass:
+ * reads S (`pre`) once, writes g once.  P comes dense (periph) or from a dictionary (ptab + uid). */
+typedef struct kpgnn_combine_bwd_desc {
+    int32_t N, K, D, mode;
+    const float* pre;           /* device [N,K,D] contiguous (S saved by the forward) */
+    const float* gh;            /* device [N,D] contiguous          (with theta) */
+    const float* theta;         /* device [K,D] or NULL */
+    const float* gout;          /* device [N,K,D] strided            (without theta) */
+    int64_t go_sn, go_sk;
+    const float* periph;        /* dense P [N,K,D] or NULL  (only read for gtheta) */
+    int64_t p_sn, p_sk;
+    const float* ptab;          /* dictionary P: [U,D] rows + uid, or NULL */
+    const int32_t* uid;
+    int64_t uid_stride;
+    float* g;                   /* device [N,K,D] contiguous */
+    float* gv;                  /* device [N,K,D] contiguous or NULL: dL/dP when a dense P needs its gradient */
+    float* gtheta;              /* device [K,D] (overwritten) or NULL */
+    void* workspace;            /* device, >= kpgnn_combine_bwd_workspace_bytes(N,K,D) when gtheta != NULL */
+    size_t workspace_bytes;
+} kpgnn_combine_bwd_desc;
+
+size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D);
+int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-table gather-sum: out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :].

@@ -26,6 +26,7 @@ class AggFwdDesc(ctypes.Structure):
         ("eps", c_vp),
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
+        ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
     ]
 
 
@@ -44,9 +45,24 @@ class AggBwdDesc(ctypes.Structure):
 class TableGradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i32), ("K", c_i32), ("D", c_i32), ("nodes_per_tile", c_i32), ("n_code0", c_i32), ("n_codek", c_i32),
+        ("n_dict", c_i32), ("dict_src", c_i32),
         ("tile_ptr", c_vp), ("tile_pack", c_vp),
         ("g", c_vp), ("g_sn", c_i64), ("g_sk", c_i64),
-        ("gtable0", c_vp), ("gtablek", c_vp),
+        ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp),
+        ("gtable0", c_vp), ("gtablek", c_vp), ("gdict", c_vp),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class CombineBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("mode", c_i32),
+        ("pre", c_vp), ("gh", c_vp), ("theta", c_vp),
+        ("gout", c_vp), ("go_sn", c_i64), ("go_sk", c_i64),
+        ("periph", c_vp), ("p_sn", c_i64), ("p_sk", c_i64),
+        ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
+        ("g", c_vp), ("gv", c_vp), ("gtheta", c_vp),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -70,7 +86,10 @@ SIGNATURES = {
                                        c_vp, ctypes.c_size_t, c_vp]),
     "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
+    "kpgnn_table_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 7),
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
+    "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),
+    "kpgnn_combine_bwd": (ctypes.c_int, [ctypes.POINTER(CombineBwdDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

@@ -15,7 +15,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
-from .ops import table_gather_sum
+from .ops import DictPeripheral, table_gather_sum
+
+MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
 
 _PIDX = "_kpgnn_packed_peripheral"
 
@@ -28,7 +30,7 @@ def _packed_peripheral_index(pea, pca, sizes):
     key = (None if pea is None else pea._version, None if pca is None else (id(pca), pca._version), tuple(sizes))
     rec = getattr(anchor, _PIDX, None)
     if rec is not None and rec[0] == key:
-        return rec[1], rec[2]
+        return rec[1:]
     cols, table_of_col = [], []
     starts = [0]
     for n in sizes:
@@ -52,11 +54,20 @@ def _packed_peripheral_index(pea, pca, sizes):
     idx = idx64.to(torch.int16) if max(sizes) <= 32768 else (idx64 - 65536 * (idx64 >= 32768)).to(torch.int16)
     col_offset = torch.tensor([starts[t] for t in table_of_col], dtype=torch.int32, device=idx64.device)
     idx = idx.contiguous()
+    # dictionary encoding of the (node,hop) tuples (one sort per batch object)
+    uidx = uid = None
+    if idx64.numel():
+        u64, inv = torch.unique(idx64, dim=0, return_inverse=True)
+        if u64.shape[0] <= MAX_DICT_ROWS:
+            uidx = (u64.to(torch.int16) if max(sizes) <= 32768 else (u64 - 65536 * (u64 >= 32768)).to(torch.int16)).contiguous()
+            n_nodes = (pea if pea is not None else pca).shape[0]
+            uid = inv.to(torch.int32).view(n_nodes, -1).contiguous()
+    rec = (key, idx, col_offset, uidx, uid)
     try:
-        setattr(anchor, _PIDX, (key, idx, col_offset))
+        setattr(anchor, _PIDX, rec)
     except Exception:  # pragma: no cover
         pass
-    return idx, col_offset
+    return rec[1:]
 
 
 # ------------------------------------------------------------------------------------------------ small pieces
@@ -236,9 +247,13 @@ class _KHopBody(nn.Module):
                 tables.append(g * (emb.weight @ enc.proj.weight[:, c * W:(c + 1) * W].t()))
                 sizes.append(emb.num_embeddings)
             bias = bias + g * enc.proj.bias
-        idx, col_offset = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
-        out = table_gather_sum(torch.cat(tables, dim=0), bias, idx, col_offset)
-        return out.view(num_nodes, -1, W)
+        idx, col_offset, uidx, uid = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
+        table = torch.cat(tables, dim=0)
+        if uidx is not None:
+            # dictionary form: the distinct index tuples are few (25 for a 2048-molecule batch), so P is a
+            # [U,W] table + a static int32 uid per (node,hop); the layers' kernels read / differentiate that
+            return DictPeripheral(table_gather_sum(table, bias, uidx, col_offset), uid)
+        return table_gather_sum(table, bias, idx, col_offset).view(num_nodes, -1, W)
 
     def _vn_init(self, batch, edge_index):
         idx = torch.zeros(int(batch[-1].item()) + 1, dtype=edge_index.dtype, device=edge_index.device)

@@ -70,6 +70,7 @@ struct FwdParams {
     const float* theta;
     float* hout;
     const float* xbias;
+    const float* ptab; const int32_t* uid; int64_t uid_stride;
 };
 
 // TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
@@ -166,6 +167,7 @@ agg_fwd_kernel(const FwdParams p) {
             if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
+            else if (p.uid) v.add(V<VEC>::load(p.ptab + (int64_t)p.uid[i * p.uid_stride + k] * D + c0));
             if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
             if (COMBINE) {
                 const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
@@ -410,7 +412,9 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.table0 = d->table0; p.tablek = d->tablek;
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
-    const int vec = pick_vec(d->D, {d->x, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias},
+    p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
+    KPGNN_REQUIRE(p.uid == nullptr || (p.ptab != nullptr && p.uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
+    const int vec = pick_vec(d->D, {d->x, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
                              {d->x_sn, d->x_sk, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
                               d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;

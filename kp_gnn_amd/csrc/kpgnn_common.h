@@ -50,6 +50,11 @@ struct DeviceFacts {
 };
 const DeviceFacts& device_facts();
 
+// out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
+// destination arrays of n0 / n1 / rest elements (table_grad.hip).
+int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
+                float* out2, hipStream_t s);
+
 // XCD-aware tile order.  Blocks b and b+8 share an XCD (own L2).  The tile range is cut into 8
 // contiguous slabs, one per XCD, and the blocks of one XCD walk their slab tile by tile, so that
 // the rows a slab's graphs gather stay inside one 4 MiB L2.  Placement only affects speed.

@@ -78,7 +78,33 @@ def _check_codes(csr, k_act, table0, tablek):
         raise IndexError(f"edge code {csr.max_codek} out of range for hopk_edge_emb with {tablek.shape[0]} rows")
 
 
-def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre):
+class DictPeripheral:
+    """Dictionary form of the peripheral features: P[i,k,:] = table[uid[i,k], :].
+
+    The (node,hop) peripheral-subgraph feature tuples repeat massively (25 distinct among 379,600 slots of a
+    2048-molecule batch), so instead of a dense [N,K,D] tensor the callers may hand the layers this object
+    as `peripheral_attr`: `table` [U,D] carries the gradient, `uid` [N,K] (int32) is static per batch.
+    Supports the body's `peripheral_attr[:, :k]` hop-prefix slicing (models/GNNs.py:421-423)."""
+
+    def __init__(self, table, uid):
+        self.table, self.uid = table, uid
+
+    @property
+    def shape(self):
+        return (self.uid.shape[0], self.uid.shape[1], self.table.shape[1])
+
+    def __getitem__(self, idx):
+        if (isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], slice)
+                and idx[1].start in (None, 0) and idx[1].step in (None, 1)):
+            return DictPeripheral(self.table, self.uid[:, idx[1]])
+        return self.dense()[idx]
+
+    def dense(self):
+        """Materialised [N,K,D] tensor (differentiable): for callers outside the fused kernels."""
+        return DictRows.apply(self.table, self.uid)
+
+
+def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None):
     """Launch kpgnn_aggregate_fwd.  Returns (out or hout, pre or None)."""
     lib = _lib.load()
     N, K, D = x.shape
@@ -96,6 +122,8 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     d.table0, d.tablek = _ptr(table0), _ptr(tablek)
     if periph is not None:
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
+    elif uid is not None:
+        d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
     pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
@@ -113,9 +141,10 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(x)), "kpgnn_aggregate_fwd")
         if _timer is not None:
             e1.record()
-            n_t = 1 + (periph is not None) + (pre is not None) + (theta is None)  # x, P, pre, out
-            _timer.records.append(("agg_fwd", algorithmic_bytes(csr, K, D, n_t, d.n_code0 + d.n_codek,
-                                                                extra_nd=1 if theta is not None else 0), e0, e1))
+            n_t = 1 + (periph is not None) + (pre is not None) + (theta is None)  # x, dense P, pre, out
+            extra = 4 * N * K if uid is not None else 0                           # int32 uid per (node,hop)
+            _timer.records.append(("agg_fwd", extra + algorithmic_bytes(csr, K, D, n_t, d.n_code0 + d.n_codek,
+                                                                        extra_nd=1 if theta is not None else 0), e0, e1))
     return out, pre
 
 
@@ -153,18 +182,36 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
     return gx, gt0, gtk
 
 
-def table_grad_raw(csr, g, n_code0, n_codek):
-    """Launch kpgnn_table_grad: edge-code table gradients of g = dL/dS [N,k,D] (no per-edge atomics)."""
+def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None):
+    """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
+    or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
+    Returns (gtable0, gtablek, gdict), or None when the tables do not fit the LDS-resident kernel."""
     lib = _lib.load()
     N, K, D = g.shape
     dev = g.device
+    n0 = n_code0 if edges else 0
+    nk = n_codek if (edges and K > 1) else 0
+    ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n0, 1) if edges else 0, nk, n_dict)
+    if ws_bytes == 0:
+        return None
     d = _lib.TableGradDesc()
-    d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, n_codek
-    d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
+    d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n0, nk
+    d.n_dict = n_dict
+    d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
+    if edges:
+        d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
     d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
-    gt0 = torch.zeros((n_code0, D), dtype=torch.float32, device=dev)
-    gtk = torch.zeros((n_codek, D), dtype=torch.float32, device=dev) if (K > 1 and n_codek > 0) else None
-    d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
+    gt0 = gtk = gd = None
+    if edges:
+        gt0 = torch.empty((n0, D), dtype=torch.float32, device=dev)
+        gtk = torch.empty((nk, D), dtype=torch.float32, device=dev) if nk > 0 else None
+        d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
+    if n_dict > 0:
+        gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
+        d.uid, d.uid_stride, d.gdict = uid.data_ptr(), uid.stride(0), gd.data_ptr()
+        d.theta, d.gh = _ptr(theta), _ptr(gh)
+    ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -172,82 +219,134 @@ def table_grad_raw(csr, g, n_code0, n_codek):
         _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(g)), "kpgnn_table_grad")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("table_grad", 4 * N * K * D + 4 * csr.active_pairs(K) + 4 * D * (n_code0 + n_codek),
-                                   e0, e1))
-    return gt0, gtk
+            _timer.records.append(("table_grad", 4 * N * K * D + (4 * csr.active_pairs(K) if edges else 0)
+                                   + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0), e0, e1))
+    return gt0, gtk, gd
 
 
-def _gelu_grad(pre):
-    # d/ds [0.5 s (1 + erf(s/sqrt2))] = Phi(s) + s phi(s)
-    return 0.5 * (1.0 + torch.erf(pre * _SQRT1_2)) + pre * torch.exp(-0.5 * pre * pre) * _INV_SQRT_2PI
+def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want_gv):
+    """Launch kpgnn_combine_bwd.  gout is gh [N,D] when theta is given, else dL/dout [N,K,D].
+    Returns (g, gv or None, gtheta or None)."""
+    lib = _lib.load()
+    N, K, D = pre.shape
+    dev = pre.device
+    d = _lib.CombineBwdDesc()
+    d.N, d.K, d.D, d.mode = N, K, D, mode
+    d.pre = pre.data_ptr()
+    if theta is not None:
+        d.gh, d.theta = gout.data_ptr(), theta.data_ptr()
+    else:
+        d.gout, d.go_sn, d.go_sk = gout.data_ptr(), gout.stride(0), gout.stride(1)
+    if periph is not None:
+        d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
+    elif uid is not None:
+        d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
+    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
+    gth = torch.empty((K, D), dtype=torch.float32, device=dev) if want_gtheta else None
+    d.g, d.gv, d.gtheta = g.data_ptr(), _ptr(gv), _ptr(gth)
+    ws = None
+    if want_gtheta:
+        nb = lib.kpgnn_combine_bwd_workspace_bytes(N, K, D)
+        ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(nb)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_combine_bwd(ctypes.byref(d), _stream(pre)), "kpgnn_combine_bwd")
+        if _timer is not None:
+            e1.record()
+            n_t = 2 + (gv is not None) + (theta is None) + (periph is not None and want_gtheta)
+            _timer.records.append(("combine_bwd", 4 * N * K * D * n_t + (4 * N * D if theta is not None else 0), e0, e1))
+    return g, gv, gth
 
 
 class KHopAggregate(torch.autograd.Function):
     """out[N,k,D] (or hout[N,D] with a fused geometric combine) = epilogue(K-hop segmented sum).
 
-    Differentiable w.r.t. x, table0, tablek, periph, eps, theta.  `xbias` (a detached constant row, see
-    kpgnn.h) carries no gradient: it is the padding row of hopk_node_path_emb, whose grad the reference's
-    nn.Embedding(padding_idx=0) discards as well."""
+    Differentiable w.r.t. x, table0, tablek, periph (dense) or ptab (dictionary), eps, theta.  `xbias` (a
+    detached constant row, see kpgnn.h) carries no gradient: it is the padding row of hopk_node_path_emb,
+    whose grad the reference's nn.Embedding(padding_idx=0) discards as well.
+
+    Backward = three HIP launches: kpgnn_combine_bwd (g = dL/dS, theta grad) when the epilogue has an
+    activation or a fused combine, kpgnn_table_grad (edge-code table + dictionary grads, no atomics),
+    kpgnn_aggregate_bwd (the transposed gather for dL/dx)."""
 
     @staticmethod
-    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, csr, k_act, mode):
-        _require_cuda(x, table0, tablek, periph, eps, theta, xbias)
+    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid):
+        _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid)
         x = _last_contig(x.float())
         if periph is not None:
             periph = _last_contig(periph.float())
+            ptab = uid = None
         if table0 is not None:
             table0 = table0.contiguous()
             tablek = tablek.contiguous() if tablek is not None else None
             _check_codes(csr, k_act, table0, tablek)
         if theta is not None:
             theta = theta.contiguous()
+        if ptab is not None:
+            ptab = ptab.contiguous()
         need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
-        out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre)
-        ctx.csr, ctx.k_act, ctx.mode = csr, k_act, mode
+        out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre,
+                                     ptab=ptab, uid=uid)
+        ctx.csr, ctx.k_act, ctx.mode, ctx.uid = csr, k_act, mode, uid
         ctx.has_tables = table0 is not None
         ctx.n_code0 = table0.shape[0] if table0 is not None else 0
         ctx.n_codek = tablek.shape[0] if tablek is not None else 0
         ctx.has_periph = periph is not None
+        ctx.n_dict = ptab.shape[0] if ptab is not None else 0
         eps_needs = eps is not None and eps.requires_grad
         ctx.save_for_backward(pre, eps, theta, periph if theta is not None else None,
-                              x if eps_needs else None, xbias if eps_needs else None)
+                              x if eps_needs else None, xbias if eps_needs else None,
+                              ptab if theta is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        pre, eps, theta, periph, x_saved, xbias = ctx.saved_tensors
-        mode = ctx.mode
-        gtheta = None
-        if theta is not None:
-            # hout = sum_k theta[k] * v[k],  v = act(S) + P
-            gout = gout.contiguous()
-            if mode == MODE_GINPLUS:
-                act = torch.nn.functional.gelu(pre)
-            elif mode == MODE_GCN:
-                act = torch.relu(pre)
-            else:
-                act = pre
-            v = act if periph is None else act + periph
-            gtheta = torch.einsum("nd,nkd->kd", gout, v)
-            gv = gout.unsqueeze(1) * theta.unsqueeze(0)
+        pre, eps, theta, periph, x_saved, xbias, ptab = ctx.saved_tensors
+        mode, csr, k_act, uid = ctx.mode, ctx.csr, ctx.k_act, ctx.uid
+        fused = theta is not None
+        need_act = mode in (MODE_GINPLUS, MODE_GCN)
+        want_gperiph = ctx.has_periph and ctx.needs_input_grad[3]
+        want_gdict = ctx.n_dict > 0 and ctx.needs_input_grad[7]
+        gtheta = gperiph = gdict = None
+        gout = gout.contiguous() if fused else _last_contig(gout)
+        if fused or need_act:
+            g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
+                                            want_gtheta=fused and ctx.needs_input_grad[5],
+                                            want_gv=fused and want_gperiph)
+            gperiph = gv if fused else (gout if want_gperiph else None)
         else:
-            gv = _last_contig(gout)
-        gperiph = gv if ctx.has_periph else None
-        if mode == MODE_GINPLUS:
-            g = gv * _gelu_grad(pre)
-        elif mode == MODE_GCN:
-            g = gv * (pre > 0).to(gv.dtype)
-        else:
-            g = gv
-        g = _last_contig(g)
+            g = gout
+            gperiph = gout if want_gperiph else None
+        # --- table gradients (edge codes + peripheral dictionary), column-private kernel
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
-        if want_tables and mode != MODE_GCN:
-            # table grads by the column-private streaming kernel; the gather then runs without atomics
-            gt0, gtk = table_grad_raw(ctx.csr, g, ctx.n_code0, ctx.n_codek)
-            gx, _, _ = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, False)
-        else:  # GCN weights its table grads per edge (dis[src]*dis[dst]): fused path
-            gx, gt0, gtk = aggregate_bwd_raw(ctx.csr, ctx.k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, want_tables)
+        tables_in_gather = False
+        if want_tables or want_gdict:
+            edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
+            dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
+            res = None
+            if edges_here or dict_here:
+                res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
+                                     uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
+                                     theta=theta if fused else None, gh=gout if fused else None)
+            if res is not None:
+                gt0, gtk, gdict = res
+            if want_tables and (res is None or not edges_here):
+                tables_in_gather = True
+            if want_gdict and gdict is None:  # activation without fused combine (or oversize tables): dL/dP = gout
+                r2 = table_grad_raw(csr, gout if not fused else (gout.unsqueeze(1) * theta.unsqueeze(0)),
+                                    0, 0, edges=False, uid=uid, n_dict=ctx.n_dict)
+                if r2 is None:
+                    raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
+                                          "pass a dense peripheral_attr instead")
+                gdict = r2[2]
+        gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather)
+        if tables_in_gather:
+            gt0, gtk = a0, ak
         geps = None
         if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
             xe = x_saved
@@ -256,12 +355,39 @@ class KHopAggregate(torch.autograd.Function):
             geps = (g * xe).sum().reshape(eps.shape)
         # (row 0 of both table grads stays exactly zero: code 0 == "inactive" never enters the CSR, which
         #  is also what nn.Embedding(padding_idx=0) would do)
-        return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta,
+        return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta, None, gdict,
                 None, None, None, None)
 
 
 def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None):
-    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, csr, k_act, mode)
+    """periph: dense [N,k,D] tensor, a DictPeripheral, or None."""
+    ptab = uid = None
+    if isinstance(periph, DictPeripheral):
+        ptab, uid, periph = periph.table, periph.uid, None
+    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid)
+
+
+class DictRows(torch.autograd.Function):
+    """out[i,k,:] = table[uid[i,k],:]; backward through kpgnn_table_grad (dictionary part, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, table, uid):
+        ctx.save_for_backward(uid)
+        ctx.n = table.shape[0]
+        return table.index_select(0, uid.reshape(-1).long()).view(uid.shape[0], uid.shape[1], table.shape[1])
+
+    @staticmethod
+    def backward(ctx, gout):
+        (uid,) = ctx.saved_tensors
+        gout = _last_contig(gout)
+
+        class _C:  # table_grad_raw only needs the tile size from the CSR when there is no pair list
+            nodes_per_tile = 8 if gout.shape[1] <= 8 else max(1, 64 // gout.shape[1])
+        res = table_grad_raw(_C, gout, 0, 0, edges=False, uid=uid, n_dict=ctx.n)
+        if res is None:
+            g = torch.zeros((ctx.n, gout.shape[2]), dtype=gout.dtype, device=gout.device)
+            return g.index_add_(0, uid.reshape(-1).long(), gout.reshape(-1, gout.shape[2])), None
+        return res[2], None
 
 
 # ------------------------------------------------------------------------------------------------ table gather-sum

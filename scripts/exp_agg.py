@@ -36,6 +36,7 @@ for k in (8, 4, 1):
     r["fwd notab noP (sum)"] = timeit(lambda: ops.aggregate_fwd_raw(csr, k, _lib.MODE_SUM, xs, None, None, None, None, None, None, False))
     r["bwd tables"] = timeit(lambda: ops.aggregate_bwd_raw(csr, k, M, gs, None, 5, 52, True))
     r["bwd no tables"] = timeit(lambda: ops.aggregate_bwd_raw(csr, k, M, gs, None, 5, 52, False))
+    r["table_grad"] = timeit(lambda: ops.table_grad_raw(csr, gs, 5, 52))
     cp = timeit(lambda: gs.clone())
     print(f"k={k}: " + "  ".join(f"{n}={v:.0f}us" for n, v in r.items()) + f"  | clone[N,k,D]={cp:.0f}us")
 # table gather-sum

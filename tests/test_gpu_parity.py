@@ -366,3 +366,38 @@ def test_tile_sorted_pair_list_is_a_permutation_of_the_csr():
     assert got == want
     key = (tile_of.astype(np.int64) << 17) | (table.astype(np.int64) << 16) | code
     assert (np.diff(key) >= 0).all()
+
+
+@pytest.mark.parametrize("kind,combine", [("KPGIN", "geometric"), ("KPGINPlus", "geometric"), ("KPGINPlus", "attention"),
+                                          ("KPGCN", "geometric"), ("KPGCN", "attention")])
+def test_dictionary_peripheral_equals_dense(kind, combine):
+    """peripheral_attr as a DictPeripheral (table + uid) gives the same outputs and gradients as the dense tensor."""
+    from kp_gnn_amd import layers as L
+    from kp_gnn_amd.ops import DictPeripheral
+    dev = _dev()
+    N, E, K, H = 57, 500, 4, 24
+    ei, ea = _random_khop(N, E, K, seed=31, n0=4, nk=8)
+    ei, ea = ei.to(dev), ea.to(dev)
+    torch.manual_seed(5)
+    cls = {"KPGIN": L.KPGINConv, "KPGINPlus": L.KPGINPlusConv, "KPGCN": L.KPGCNConv}[kind]
+    layer = cls(H, H, K, num_hop1_edge=2, num_pe=8, combine=combine).to(dev)
+    W = H if kind == "KPGINPlus" else H // K
+    U = 7
+    table = torch.randn(U, W, device=dev)
+    uid = torch.randint(0, U, (N, K), device=dev, dtype=torch.int32)
+    x = torch.randn(N, K, H, device=dev) if kind == "KPGINPlus" else torch.randn(N, H, device=dev)
+    w = torch.randn(N, H, device=dev)
+    res = []
+    for use_dict in (False, True):
+        layer.zero_grad()
+        t = table.clone().requires_grad_(True)
+        xx = x.clone().requires_grad_(True)
+        P = DictPeripheral(t, uid) if use_dict else t[uid.long()]
+        out = layer(xx, ei, ea, None, P)
+        (out * w).sum().backward()
+        res.append((out.detach(), xx.grad, t.grad, {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}))
+    _close(res[1][0], res[0][0], "out")
+    _close(res[1][1], res[0][1], "grad_x")
+    _close(res[1][2], res[0][2], "grad_table", atol=3e-5)
+    for k in res[0][3]:
+        _close(res[1][3][k], res[0][3][k], "grad " + k, atol=3e-5)
