@@ -25,6 +25,7 @@ import time
 
 import torch
 
+dp = None
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -53,24 +54,12 @@ def build_model(args, device):
     return model.to(device).train()
 
 
-def flatten_grads(model):
-    """Make every .grad a view of ONE flat fp32 bucket, so the data-parallel step is a single all-reduce."""
-    params = [p for p in model.parameters() if p.requires_grad]
-    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
-    off = 0
-    for p in params:
-        p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
-    return flat
-
-
 def train_step(model, batch, opt, flat_grad, world):
     flat_grad.zero_()
     score = model(batch)
     loss = (score.squeeze() - batch.y.squeeze()).abs().mean()  # train_ZINC.py:42
     loss.backward()
-    if world > 1:
-        torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.AVG)
+    dp.allreduce_mean(flat_grad, world)
     opt.step()
     return loss
 
@@ -145,6 +134,8 @@ def main():
 
     from kp_gnn_amd import ops
     from kp_gnn_amd.batch import synthetic_zinc_batch
+    global dp
+    from kp_gnn_amd import dp
 
     threads = max(1, usable_cpus() // max(1, min(world, 8)))
     torch.set_num_threads(threads)
@@ -153,7 +144,7 @@ def main():
     t_data = time.perf_counter()
     batches = []
     for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
-        seed0 = (rank * args.num_batches + i) * args.batch
+        seed0 = dp.shard_seed(rank, args.num_batches, i, args.batch)
         b = synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K, num_threads=threads).to(device)
         b.build_csr()
         batches.append(b)
@@ -164,11 +155,10 @@ def main():
             f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]})")
 
     model = build_model(args, device)
-    flat_grad = flatten_grads(model)
+    flat_grad = dp.flatten_grads(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
     if world > 1:  # identical replicas
-        for p in list(model.parameters()) + list(model.buffers()):
-            torch.distributed.broadcast(p.data, 0)
+        dp.broadcast_model(model)
 
     def barrier():
         torch.cuda.synchronize()
@@ -194,10 +184,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_launch_timer(None)
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dp.max_over_ranks(elapsed, device, world)
     final_loss = float(loss.item())
     if rank == 0:
         log(f"timed {args.steps} steps in {elapsed:.3f}s")

@@ -11,20 +11,24 @@
 // to the thread's own LDS slot when the code changes.  g is streamed once, coalesced (a row = D floats),
 // the next tile's loads are in flight while the current tile is walked, and the pair list is wave-uniform
 // (scalar loads).  Per-block partial tables go to a workspace slab with plain stores; a second launch adds
-// the slabs in block order, so the result is deterministic (bitwise reproducible).
+// the slabs in block order (deterministic; only the few per-tile LDS flushes of the walker groups race).
+#include <cstdlib>
+
 #include "kpgnn_common.h"
 
 namespace kpgnn {
 namespace {
 
-constexpr int kCols = 128;    // threads per block = feature columns per block
-constexpr int kMaxRows = 64;  // tile rows held in registers while the previous tile is being walked
+constexpr int kCols = 128;    // feature columns per block (one walker group = kCols threads = 2 waves)
+constexpr int kGroups = 4;    // walker groups per block: each walks a quarter of the tile's pair list
+constexpr int kThreadsTG = kCols * kGroups;
+constexpr int kMaxRows = 64;  // NT*K: at most 8 nodes x 8 hops per tile
 
 struct TgParams {
     int N, K, D, NT, n0, nk, U, dict_src;
     const int32_t* tptr;
     const uint32_t* tpack;
-    const float* g; int64_t g_sn, g_sk;
+    const float* g;
     // peripheral dictionary (optional): gdict[uid[i*uid_stride + k]] += theta[k,:] * gh[i,:]
     const int32_t* uid; int64_t uid_stride;
     const float* theta;
@@ -32,102 +36,148 @@ struct TgParams {
     float* slab;          // [gridDim.x][n0 + nk + U][D]
 };
 
-// Load one tile's column-t values into registers (rows beyond the tile / past N read as 0).
-__device__ __forceinline__ void load_tile_regs(const TgParams& p, int64_t tl, int d, bool col_ok, int rows,
-                                               float (&v)[kMaxRows]) {
-    const int64_t node0 = tl * p.NT;
-#pragma unroll
-    for (int r = 0; r < kMaxRows; ++r) {
-        v[r] = 0.f;
-        if (r < rows) {
-            const int64_t node = node0 + r / p.K;
-            const int hop = r % p.K;
-            if (node < p.N && col_ok) v[r] = p.g[node * p.g_sn + (int64_t)hop * p.g_sk + d];
-        }
-    }
-}
-
-__global__ void __launch_bounds__(kCols)
+// g must be contiguous [N,K,D]: a tile of NT nodes is then one contiguous run of NT*K*D floats, copied to
+// LDS as is (16-B loads when D % 4 == 0); thread t reads column d of row r at tile[r*D + d] (bank = d).
+// The kGroups walker groups share the tile and the accumulator table; a group keeps the running sum of ITS
+// current code in a register and flushes it with an LDS atomic (a code can straddle two groups' chunks; the
+// flushes are a handful per tile, so the atomics cost nothing - unlike one atomic per edge).
+template <bool VEC4>
+__global__ void __launch_bounds__(kThreadsTG)
 table_grad_kernel(const TgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int t = threadIdx.x;
+    const int grp = threadIdx.x / kCols;
+    const int t = threadIdx.x % kCols;
+    const int lane = t & 63;
     const int d = blockIdx.y * kCols + t;
     const bool col_ok = d < p.D;
-    const int rows = p.NT * p.K;                     // <= kMaxRows (checked by the launcher)
+    const int dc = col_ok ? d : 0;                   // clamped column for address arithmetic
+    const int D = p.D;
     const int R = p.n0 + p.nk + p.U;
-    float* tile = lds;                               // [rows][kCols]
-    float* acc = lds + rows * kCols;                 // [R][kCols], column-private
-    for (int r = 0; r < R; ++r) acc[r * kCols + t] = 0.f;
+    const int tile_floats = p.NT * p.K * D;
+    float* tile = lds;                               // [NT*K][D]
+    float* acc = lds + ((tile_floats + 3) & ~3);     // [R][kCols], column-private
+    float* ghs = acc + R * kCols;                    // [8][kCols]
+    for (int r = grp; r < R; r += kGroups) acc[r * kCols + t] = 0.f;
     const int64_t num_tiles = ((int64_t)p.N + p.NT - 1) / p.NT;
+    const int64_t total = (int64_t)p.N * p.K * D;
     int cur = -1;       // current accumulator row (table offset + code), -1 = none
     float run = 0.f;
     int ucur = -1;      // current dictionary row
     float urun = 0.f;
-    float v[kMaxRows];
-    int64_t tl = blockIdx.x;
-    if (tl < num_tiles) load_tile_regs(p, tl, d, col_ok, rows, v);
-    for (; tl < num_tiles; tl += gridDim.x) {
-        int beg = 0, end = 0;                        // uniform (scalar) loads, ahead of the prefetch
+    float th[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) th[k] = (p.dict_src == 1 && k < p.K && col_ok) ? p.theta[k * D + d] : 0.f;
+    constexpr int kPref = 4;
+    float4 pref[kPref];
+    if (VEC4) {
+#pragma unroll
+        for (int q = 0; q < kPref; ++q) {
+            const int64_t i = (int64_t)blockIdx.x * tile_floats + (q * kThreadsTG + threadIdx.x) * 4;
+            pref[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (blockIdx.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * 4 < tile_floats)
+                pref[q] = *reinterpret_cast<const float4*>(p.g + i);
+        }
+    }
+    for (int64_t tl = blockIdx.x; tl < num_tiles; tl += gridDim.x) {
+        int beg = 0, end = 0;
         if (p.tptr) { beg = p.tptr[tl]; end = p.tptr[tl + 1]; }
+        const int64_t base = tl * tile_floats;
+        const int nfl = (int)min((int64_t)tile_floats, total - base);
         __syncthreads();                             // previous tile fully walked
+        if (VEC4) {
+            // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
-        for (int r = 0; r < kMaxRows; ++r)
-            if (r < rows) tile[r * kCols + t] = v[r];
-        __syncthreads();
-        if (tl + gridDim.x < num_tiles)              // next tile's loads fly while this tile is walked
-            load_tile_regs(p, tl + gridDim.x, d, col_ok, rows, v);
-        // ---- walk the (table,code)-sorted pair list of this tile; the list is wave-uniform -> scalar loads
-        for (int e0 = beg; e0 < end; e0 += 8) {
-            uint32_t en[8]; float val[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) en[u] = p.tpack[min(e0 + u, end - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int hop = en[u] & 0xFFF;
-                const int nit = (en[u] >> 12) & 7;
-                const bool ok = (e0 + u < end) && hop < p.K;
-                val[u] = tile[(ok ? (nit * p.K + hop) : 0) * kCols + t];
+            for (int q = 0; q < kPref; ++q) {
+                const int i = (q * kThreadsTG + threadIdx.x) * 4;
+                if (i < nfl) *reinterpret_cast<float4*>(tile + i) = pref[q];
             }
+            for (int i = (kPref * kThreadsTG + threadIdx.x) * 4; i < nfl; i += kThreadsTG * 4)
+                *reinterpret_cast<float4*>(tile + i) = *reinterpret_cast<const float4*>(p.g + base + i);
+            const int64_t nb = base + (int64_t)gridDim.x * tile_floats;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int hop = en[u] & 0xFFF;
-                if (e0 + u < end && hop < p.K) {
-                    const int cc = (int)(en[u] >> 15);                 // table<<16 | code
-                    const int row = (cc >> 16) ? p.n0 + (cc & 0xFFFF) : cc;
-                    if (row != cur) {                                  // wave-uniform
-                        if (cur >= 0) acc[cur * kCols + t] += run;
-                        cur = row;
-                        run = 0.f;
+            for (int q = 0; q < kPref; ++q) {
+                const int64_t i = nb + (q * kThreadsTG + threadIdx.x) * 4;
+                if (tl + gridDim.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * 4 < tile_floats)
+                    pref[q] = *reinterpret_cast<const float4*>(p.g + i);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nfl; i += kThreadsTG) tile[i] = p.g[base + i];
+        }
+        {   // this group's contiguous chunk of the sorted pair list (multiple of 8 entries except the tail)
+            const int len = end - beg;
+            const int per = ((len + kGroups - 1) / kGroups + 7) & ~7;
+            beg = min(end, beg + grp * per);
+            end = min(end, beg + per);
+        }
+        uint32_t nxt = (beg + lane < end) ? p.tpack[beg + lane] : 0xFFFFFFFFu;   // hop 0xFFF == skip
+        if (p.dict_src == 1) {                       // gh rows of the tile's nodes, column t
+            for (int n = grp; n < p.NT; n += kGroups) {
+                const int64_t node = tl * p.NT + n;
+                ghs[n * kCols + t] = (node < p.N && col_ok) ? p.gh[node * D + d] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- walk the (table,code)-sorted pair list of this tile.  Each wave fetches 64 entries with ONE
+        //      coalesced load (lane l holds entry l) and broadcasts them with v_readlane (SGPR, no LDS, no
+        //      scalar-cache misses); the LDS tile reads of 8 entries are issued back to back before the
+        //      (sequential, register-only) run accumulation.  The next chunk is fetched while this one is walked.
+        for (int b0 = beg; b0 < end; b0 += 64) {
+            const uint32_t mine = nxt;
+            if (b0 + 64 < end) nxt = (b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu;
+            const int cnt = min(64, end - b0);
+            for (int e0 = 0; e0 < cnt; e0 += 8) {
+                uint32_t en[8]; float val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) en[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine, e0 + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int hop = en[u] & 0xFFF;
+                    const int nit = (en[u] >> 12) & 7;
+                    val[u] = tile[(hop < p.K ? (nit * p.K + hop) : 0) * D + dc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if ((int)(en[u] & 0xFFF) < p.K) {
+                        const int cc = (int)(en[u] >> 15);                 // table<<16 | code
+                        const int row = (cc >> 16) ? p.n0 + (cc & 0xFFFF) : cc;
+                        if (row != cur) {                                  // wave-uniform
+                            if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
+                            cur = row;
+                            run = 0.f;
+                        }
+                        run += val[u];
                     }
-                    run += val[u];
                 }
             }
         }
-        // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register
+        // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register;
+        //      theta / gh sit in registers, the (wave-uniform) uids of a node are fetched together
         if (p.U > 0) {
             const int64_t node0 = tl * p.NT;
-            for (int n = 0; n < p.NT; ++n) {
-                const int64_t node = node0 + n;
-                if (node >= p.N) break;
-                const float ghv = (p.dict_src == 1 && col_ok) ? p.gh[node * p.D + d] : 0.f;
-                for (int k = 0; k < p.K; ++k) {
-                    const int u = p.uid[node * p.uid_stride + k];      // uniform
+            for (int n = grp; n < p.NT && node0 + n < p.N; n += kGroups) {
+                const float ghv = ghs[n * kCols + t];
+                const int32_t* up = p.uid + (node0 + n) * p.uid_stride;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k >= p.K) break;
+                    const int u = up[k];                                // wave-uniform
                     if (u != ucur) {
-                        if (ucur >= 0) acc[(p.n0 + p.nk + ucur) * kCols + t] += urun;
+                        if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
                         ucur = u;
                         urun = 0.f;
                     }
-                    if (p.dict_src == 1) urun = fmaf(col_ok ? p.theta[k * p.D + d] : 0.f, ghv, urun);
-                    else urun += tile[(n * p.K + k) * kCols + t];
+                    if (p.dict_src == 1) urun = fmaf(th[k], ghv, urun);
+                    else urun += tile[(n * p.K + k) * D + dc];
                 }
             }
         }
     }
-    if (cur >= 0) acc[cur * kCols + t] += run;
-    if (ucur >= 0) acc[(p.n0 + p.nk + ucur) * kCols + t] += urun;
+    if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
+    if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
+    __syncthreads();
     if (col_ok) {
-        float* out = p.slab + (int64_t)blockIdx.x * R * p.D + d;
-        for (int r = 0; r < R; ++r) out[(int64_t)r * p.D] = acc[r * kCols + t];
+        float* out = p.slab + (int64_t)blockIdx.x * R * D + d;
+        for (int r = grp; r < R; r += kGroups) out[(int64_t)r * D] = acc[r * kCols + t];
     }
 }
 
@@ -169,15 +219,15 @@ namespace {
 struct Plan { int grid_x, grid_y; size_t lds, ws_bytes; int R; };
 
 int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
-    if (NT * K > kMaxRows)
-        return fail(KPGNN_ELIMIT, "table_grad: nodes_per_tile*K = %d rows exceed the %d-row register tile", NT * K, kMaxRows);
+    if (NT * K > kMaxRows || K > 8 || NT > 8)
+        return fail(KPGNN_ELIMIT, "table_grad: nodes_per_tile=%d x K=%d exceeds the %d-row (8x8) register tile", NT, K, kMaxRows);
     pl->R = n0 + nk + U;
-    pl->lds = sizeof(float) * (size_t)kCols * ((size_t)NT * K + pl->R);
+    pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)kCols * (pl->R + 8));
     if (pl->lds > 160 * 1024)
         return fail(KPGNN_ELIMIT, "table_grad: %zu B of LDS needed (tile %dx%d rows + %d table rows)", pl->lds, NT, K, pl->R);
     const int64_t num_tiles = ((int64_t)N + NT - 1) / NT;
     int per_cu = (int)((160 * 1024) / pl->lds);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);  // 512-thread blocks
     int64_t gx = (int64_t)device_facts().cu_count * per_cu;
     if (gx > num_tiles) gx = num_tiles;
     if (gx < 1) gx = 1;
@@ -217,7 +267,8 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
     p.n0 = edges ? d->n_code0 : 0; p.nk = (edges && d->K > 1) ? d->n_codek : 0;
     p.U = d->n_dict; p.dict_src = d->dict_src;
-    p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g; p.g_sn = d->g_sn; p.g_sk = d->g_sk;
+    KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
+    p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
     Plan pl;
     int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl);
@@ -226,9 +277,13 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     p.slab = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (pl.lds > 64 * 1024)
-        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)table_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    hipLaunchKernelGGL(table_grad_kernel, dim3(pl.grid_x, pl.grid_y), dim3(kCols), pl.lds, s, p);
+    const bool vec4 = (p.D % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
+    if (pl.lds > 64 * 1024) {
+        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)table_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)table_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    }
+    if (vec4) hipLaunchKernelGGL(table_grad_kernel<true>, dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
+    else hipLaunchKernelGGL(table_grad_kernel<false>, dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
     KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
                        (int64_t)p.nk * p.D, d->gdict, s);

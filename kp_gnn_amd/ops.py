@@ -187,6 +187,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
     Returns (gtable0, gtablek, gdict), or None when the tables do not fit the LDS-resident kernel."""
     lib = _lib.load()
+    g = g.contiguous()
     N, K, D = g.shape
     dev = g.device
     n0 = n_code0 if edges else 0
@@ -200,7 +201,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
     if edges:
         d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
-    d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
+    d.g, d.g_sn, d.g_sk = g.data_ptr(), K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
     gt0 = gtk = gd = None
     if edges:
         gt0 = torch.empty((n0, D), dtype=torch.float32, device=dev)
@@ -239,7 +240,7 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
         d.gout, d.go_sn, d.go_sk = gout.data_ptr(), gout.stride(0), gout.stride(1)
     if periph is not None:
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
-    elif uid is not None:
+    elif uid is not None and ptab is not None:  # (P is only read for the theta gradient)
         d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
     g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
     gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None

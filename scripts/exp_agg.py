@@ -42,7 +42,7 @@ for k in (8, 4, 1):
 # table gather-sum
 from kp_gnn_amd.body import _packed_peripheral_index
 sizes = [5, 51] + [51] * 7
-idx, off = _packed_peripheral_index(b.peripheral_edge_attr, b.peripheral_configuration_attr, sizes)
+idx, off = _packed_peripheral_index(b.peripheral_edge_attr, b.peripheral_configuration_attr, sizes)[:2]
 table = torch.randn(sum(sizes), D, device=dev); bias = torch.randn(D, device=dev)
 go = torch.randn(N * K, D, device=dev)
 print("tgs fwd us", timeit(lambda: ops.TableGatherSum.apply(table, bias, idx, off)))
@@ -52,3 +52,16 @@ def f():
 print("tgs fwd+bwd us", timeit(f))
 u = torch.unique(idx, dim=0)
 print("unique peripheral tuples:", u.shape[0], "of", idx.shape[0])
+# new backward pieces
+pre = torch.randn(N, K, D, device=dev); gh = torch.randn(N, D, device=dev)
+uidx = torch.unique(idx.long(), dim=0, return_inverse=True)
+uid = uidx[1].to(torch.int32).view(N, K).contiguous(); U = uidx[0].shape[0]
+ptab = torch.randn(U, D, device=dev)
+for k in (8, 4, 1):
+    th = theta[:k].contiguous(); prek = pre[:, :k].contiguous(); uk = uid[:, :k]
+    gk = g[:, :k].contiguous()
+    a = timeit(lambda: ops.combine_bwd_raw(M, prek, gh, th, None, ptab, uk, True, False))
+    b2 = timeit(lambda: ops.table_grad_raw(csr, gk, 5, 52, edges=True, uid=uk, n_dict=U, theta=th, gh=gh))
+    c = timeit(lambda: ops.table_grad_raw(csr, gk, 5, 52, edges=True))
+    f = timeit(lambda: ops.aggregate_fwd_raw(csr, k, M, x[:, :k], t0, tk, None, None, th, None, True, ptab=ptab, uid=uk))
+    print(f"k={k}: combine_bwd={a:.0f}us table_grad(edges+dict)={b2:.0f}us table_grad(edges)={c:.0f}us fwd(dictP,theta,pre)={f:.0f}us")
