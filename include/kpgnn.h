@@ -240,6 +240,46 @@ typedef struct kpgnn_tgs_desc {
 int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
 int kpgnn_table_gather_sum_bwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm1d (+ optional ReLU) over [N, C] rows, forward and backward.  These are the
+ * nn.BatchNorm1d calls of KPGINPlusConv.mlp (KPGINplus.py:25-30), GINEConv.mlp (gine.py:31-38) and of the
+ * bodies' per-layer norm (models/GNNs.py:104,431): at C ~ 100 and N ~ 50k the framework's kernels take
+ * 100-140 us per pass (40 % of the training step); these stream the tensor at HBM speed.  Statistics are
+ * accumulated around a per-column pivot (row 0) so that E[x^2]-E[x]^2 does not cancel; partial sums leave
+ * through a per-block slab reduced in block order (deterministic).
+ *   fwd:  mean, invstd (biased var, eps) -> z = [relu]( (x-mean)*invstd*gamma + beta ); running stats updated
+ *         in place with `momentum` and the unbiased variance, exactly as nn.BatchNorm1d.
+ *   bwd:  dy = dz * [pre-activation > 0 if relu];  dbeta = sum dy; dgamma = sum dy*xhat;
+ *         dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_bn_desc {
+    int64_t N;
+    int32_t C, relu;
+    float eps, momentum;
+    const float* x;  int64_t x_stride;      /* device [N,C], row stride in elements */
+    const float* gamma; const float* beta;  /* device [C] */
+    float* running_mean; float* running_var;/* device [C], updated in place, or NULL */
+    float* mean; float* invstd;             /* device [C] outputs (saved for backward) */
+    float* z;  int64_t z_stride;            /* device [N,C] output */
+    const float* residual; int64_t r_stride;/* optional: z += residual (after the activation) */
+    void* workspace; size_t workspace_bytes;/* >= kpgnn_bn_workspace_bytes(C) */
+} kpgnn_bn_desc;
+
+typedef struct kpgnn_bn_bwd_desc {
+    int64_t N;
+    int32_t C, relu;
+    const float* x;  int64_t x_stride;
+    const float* dz; int64_t dz_stride;
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    float* dx; int64_t dx_stride;
+    float* dgamma; float* dbeta;            /* device [C] (overwritten) */
+    void* workspace; size_t workspace_bytes;
+} kpgnn_bn_bwd_desc;
+
+size_t kpgnn_bn_workspace_bytes(int32_t C);
+int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);
+int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,26 @@ class CombineBwdDesc(ctypes.Structure):
     ]
 
 
+class BnDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("C", c_i32), ("relu", c_i32), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+        ("x", c_vp), ("x_stride", c_i64), ("gamma", c_vp), ("beta", c_vp),
+        ("running_mean", c_vp), ("running_var", c_vp), ("mean", c_vp), ("invstd", c_vp),
+        ("z", c_vp), ("z_stride", c_i64), ("residual", c_vp), ("r_stride", c_i64),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class BnBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("C", c_i32), ("relu", c_i32),
+        ("x", c_vp), ("x_stride", c_i64), ("dz", c_vp), ("dz_stride", c_i64),
+        ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp), ("invstd", c_vp),
+        ("dx", c_vp), ("dx_stride", c_i64), ("dgamma", c_vp), ("dbeta", c_vp),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
 class TgsDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
@@ -90,6 +110,9 @@ SIGNATURES = {
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),
     "kpgnn_combine_bwd": (ctypes.c_int, [ctypes.POINTER(CombineBwdDesc), c_vp]),
+    "kpgnn_bn_workspace_bytes": (ctypes.c_size_t, [c_i32]),
+    "kpgnn_bn_fwd": (ctypes.c_int, [ctypes.POINTER(BnDesc), c_vp]),
+    "kpgnn_bn_bwd": (ctypes.c_int, [ctypes.POINTER(BnBwdDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .layers.gine import GINEConv
 from .ops import DictPeripheral, table_gather_sum
+from .ops_dense import batch_norm_act
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
 
@@ -142,8 +143,8 @@ class BatchNorm(nn.Module):
     def reset_parameters(self):
         self.module.reset_parameters()
 
-    def forward(self, x):
-        return self.module(x)
+    def forward(self, x, residual=None):
+        return batch_norm_act(x, self.module, relu=False, residual=residual)
 
 
 def _vn_mlp(h):
@@ -356,11 +357,13 @@ class GNNPlus(_KHopBody):
             xs = torch.stack([h_list[l - m] for m in range(k)], dim=1)  # slot m = state of layer l-m
             pek = pe_attr[:, :k - 1] if pe_attr is not None else None
             h = self.gnns[l](xs, edge_index, edge_attr[:, :k], pek, periph[:, :k])
-            h = self.norms[l](h)
+            fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
+            h = self.norms[l](h, residual=last_h if fuse_res else None)   # norm (+ residual) in one pass
             if l != self.num_layer - 1:
                 h = self.dropout(h)
             if self.residual:
-                h = h + last_h
+                if not fuse_res:
+                    h = h + last_h
                 last_h = h
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:

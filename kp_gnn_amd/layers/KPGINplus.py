@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from .._lib import MODE_GINPLUS
 from ..ops import khop_aggregate
+from ..ops_dense import mlp_linear_bn_relu_x2
 from ._base import EdgeCodeTables, KHopMessagePassing
 from .combine import GeometricCombine, make_combine
 
@@ -47,4 +48,4 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
             xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
                                 xbias=xbias)                                                  # N,k,H
             h = self.combine(xn)
-        return self.mlp(h)
+        return mlp_linear_bn_relu_x2(self.mlp, h)

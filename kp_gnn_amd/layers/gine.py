@@ -9,6 +9,7 @@ import torch.nn as nn
 from .._lib import MODE_GIN
 from ..khop_csr import get_khop_csr
 from ..ops import khop_aggregate
+from ..ops_dense import mlp_linear_bn_relu_x2
 from ._base import KHopMessagePassing
 
 
@@ -39,4 +40,4 @@ class GINEConv(KHopMessagePassing):
         csr, k_act = get_khop_csr(edge_index, edge_attr, n)
         out = khop_aggregate(x.reshape(n, 1, self.input_size), csr, k_act, MODE_GIN,
                              table0=self.hop1_edge_emb.weight, eps=self.eps)
-        return self.mlp(out.squeeze())
+        return mlp_linear_bn_relu_x2(self.mlp, out.squeeze())

@@ -1,0 +1,88 @@
+"""Dense tail of the layers: training-mode BatchNorm1d (+ReLU, +residual) on the HIP kernels of bn.hip.
+
+The nn.BatchNorm1d modules stay where the reference has them (state_dict keys `mlp.1.*`, `norms.l.module.*`);
+only their training-mode arithmetic is routed here.  Eval mode (running statistics) uses torch's own GPU op."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import _ptr, _stream
+
+
+class BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        N, C = x.shape
+        dev = x.device
+        z = torch.empty((N, C), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws_bytes = lib.kpgnn_bn_workspace_bytes(C)
+        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        d = _lib.BnDesc()
+        d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
+        d.x, d.x_stride = x.data_ptr(), x.stride(0)
+        d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+        d.running_mean, d.running_var = _ptr(running_mean), _ptr(running_var)
+        d.mean, d.invstd = stats[0].data_ptr(), stats[1].data_ptr()
+        d.z, d.z_stride = z.data_ptr(), z.stride(0)
+        if residual is not None:
+            residual = residual if residual.stride(-1) == 1 else residual.contiguous()
+            d.residual, d.r_stride = residual.data_ptr(), residual.stride(0)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, beta, stats = ctx.saved_tensors
+        lib = _lib.load()
+        dz = dz if dz.stride(-1) == 1 else dz.contiguous()
+        N, C = x.shape
+        dev = x.device
+        dx = torch.empty((N, C), dtype=torch.float32, device=dev)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws_bytes = lib.kpgnn_bn_workspace_bytes(C)
+        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        d = _lib.BnBwdDesc()
+        d.N, d.C, d.relu = N, C, 1 if ctx.relu else 0
+        d.x, d.x_stride, d.dz, d.dz_stride = x.data_ptr(), x.stride(0), dz.data_ptr(), dz.stride(0)
+        d.gamma, d.beta, d.mean, d.invstd = gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+        d.dx, d.dx_stride = dx.data_ptr(), dx.stride(0)
+        d.dgamma, d.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_bwd")
+        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None
+
+
+def batch_norm_act(x, bn, relu=False, residual=None):
+    """nn.BatchNorm1d `bn` applied to x [N,C] (+ReLU) (+residual).  Training mode with batch statistics runs
+    on the HIP kernels; everything else (eval, no affine, cumulative momentum, C > 256) on torch's GPU op."""
+    use_hip = (bn.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and bn.affine
+               and bn.momentum is not None and x.shape[1] <= 256 and x.shape[0] >= 1)
+    if use_hip:
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu)
+    out = bn(x)
+    if relu:
+        out = F.relu(out)
+    if residual is not None:
+        out = out + residual
+    return out
+
+
+def mlp_linear_bn_relu_x2(mlp, h):
+    """nn.Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) (KPGINplus.py:25-30, gine.py:31-38):
+    the two GEMMs go to hipBLASLt, each BatchNorm+ReLU pair is one fused stats/apply on the HIP kernels."""
+    h = batch_norm_act(F.linear(h, mlp[0].weight, mlp[0].bias), mlp[1], relu=True)
+    return batch_norm_act(F.linear(h, mlp[3].weight, mlp[3].bias), mlp[4], relu=True)

@@ -401,3 +401,39 @@ def test_dictionary_peripheral_equals_dense(kind, combine):
     _close(res[1][2], res[0][2], "grad_table", atol=3e-5)
     for k in res[0][3]:
         _close(res[1][3][k], res[0][3][k], "grad " + k, atol=3e-5)
+
+
+@pytest.mark.parametrize("N,C", [(1000, 104), (37, 33), (5000, 13), (2, 8), (4096, 256), (777, 6)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (False, True), (True, True)])
+def test_batch_norm_act_vs_torch(N, C, relu, res):
+    """Training-mode BatchNorm1d (+ReLU, +residual): outputs, running statistics, all gradients vs torch CPU."""
+    from kp_gnn_amd.ops_dense import batch_norm_act
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, generator=g) * 2 + 5.0   # large mean: exercises the pivoted variance
+    r = torch.randn(N, C, generator=g) if res else None
+    w = torch.randn(N, C, generator=g)
+    bn_ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.randn(C, generator=g)); bn_ref.bias.copy_(torch.randn(C, generator=g))
+    import copy
+    bn_hip = copy.deepcopy(bn_ref).to(dev)
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    out = bn_ref(xr)
+    out = torch.relu(out) if relu else out
+    out = out + rr if res else out
+    (out * w).sum().backward()
+    xd = x.clone().to(dev).requires_grad_(True)
+    rd = r.clone().to(dev).requires_grad_(True) if res else None
+    outd = batch_norm_act(xd, bn_hip, relu=relu, residual=rd)
+    (outd * w.to(dev)).sum().backward()
+    _close(outd, out, "out", atol=2e-5)
+    _close(xd.grad, xr.grad, "dx", atol=3e-5)
+    _close(bn_hip.weight.grad, bn_ref.weight.grad, "dgamma", atol=3e-5)
+    _close(bn_hip.bias.grad, bn_ref.bias.grad, "dbeta", atol=3e-5)
+    _close(bn_hip.running_mean, bn_ref.running_mean, "running_mean")
+    _close(bn_hip.running_var, bn_ref.running_var, "running_var")
+    assert int(bn_hip.num_batches_tracked) == 1
+    if res:
+        _close(rd.grad, rr.grad, "dres")
