@@ -280,6 +280,28 @@ size_t kpgnn_bn_workspace_bytes(int32_t C);
 int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);
 int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight / bias gradient of y = x W^T + b for tall-skinny activations (N ~ 50k rows, <= 256 features):
+ *   dW[o,i] = sum_r dy[r,o] * x[r,i]      db[o] = sum_r dy[r,o]
+ * i.e. the backward of the nn.Linear layers behind the aggregation (KPGINplus.py:25-30, gine.py:31-38,
+ * KPGIN.py:54,112).  The BLAS library's kernel for this K = N reduction runs at ~7 TFLOP/s (139 us);
+ * here each wave streams row PAIRS straight from HBM into v_mfma_f32_32x32x2_f32 (exact fp32: A = dy^T
+ * fragment, B = x fragment are plain coalesced row reads, no LDS), keeps a 32 x I strip of dW in
+ * accumulators, and per-block partials are added in block order (deterministic).  O, I <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_wgrad_desc {
+    int64_t N;
+    int32_t O, I;               /* out / in features */
+    const float* dy; int64_t dy_stride;   /* device [N,O] */
+    const float* x;  int64_t x_stride;    /* device [N,I] */
+    float* dw;                  /* device [O,I] contiguous (overwritten) */
+    float* db;                  /* device [O] (overwritten) or NULL */
+    void* workspace; size_t workspace_bytes;  /* >= kpgnn_wgrad_workspace_bytes(O, I) */
+} kpgnn_wgrad_desc;
+
+size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);
+int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,14 @@ class BnBwdDesc(ctypes.Structure):
     ]
 
 
+class WgradDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("O", c_i32), ("I", c_i32),
+        ("dy", c_vp), ("dy_stride", c_i64), ("x", c_vp), ("x_stride", c_i64),
+        ("dw", c_vp), ("db", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
 class TgsDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
@@ -113,6 +121,8 @@ SIGNATURES = {
     "kpgnn_bn_workspace_bytes": (ctypes.c_size_t, [c_i32]),
     "kpgnn_bn_fwd": (ctypes.c_int, [ctypes.POINTER(BnDesc), c_vp]),
     "kpgnn_bn_bwd": (ctypes.c_int, [ctypes.POINTER(BnBwdDesc), c_vp]),
+    "kpgnn_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
+    "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

@@ -63,6 +63,48 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None
 
 
+class LinearWgrad(torch.autograd.Function):
+    """y = x W^T + b with the GEMMs y and dx on the BLAS library and (dW, db) on the fp32-MFMA streaming
+    kernel kpgnn_linear_wgrad (the library's choice for that K = N reduction runs at ~7 TFLOP/s)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        N, O = dy.shape
+        I = x.shape[1]
+        dev = dy.device
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = torch.empty((O, I), dtype=torch.float32, device=dev)
+        db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        nb = lib.kpgnn_wgrad_workspace_bytes(O, I)
+        ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+        d = _lib.WgradDesc()
+        d.N, d.O, d.I = N, O, I
+        d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(d), _stream(dy)), "kpgnn_linear_wgrad")
+        return dx, dw, db
+
+
+def linear(x, lin):
+    """nn.Linear `lin` on x [N,I]; tall-skinny fp32 CUDA inputs take the MFMA weight-gradient path."""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and lin.weight.shape[0] <= 256
+            and lin.weight.shape[1] <= 256 and x.shape[0] >= 1024 and torch.is_grad_enabled()
+            and lin.weight.requires_grad):
+        return LinearWgrad.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 def batch_norm_act(x, bn, relu=False, residual=None):
     """nn.BatchNorm1d `bn` applied to x [N,C] (+ReLU) (+residual).  Training mode with batch statistics runs
     on the HIP kernels; everything else (eval, no affine, cumulative momentum, C > 256) on torch's GPU op."""
@@ -84,5 +126,5 @@ def batch_norm_act(x, bn, relu=False, residual=None):
 def mlp_linear_bn_relu_x2(mlp, h):
     """nn.Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) (KPGINplus.py:25-30, gine.py:31-38):
     the two GEMMs go to hipBLASLt, each BatchNorm+ReLU pair is one fused stats/apply on the HIP kernels."""
-    h = batch_norm_act(F.linear(h, mlp[0].weight, mlp[0].bias), mlp[1], relu=True)
-    return batch_norm_act(F.linear(h, mlp[3].weight, mlp[3].bias), mlp[4], relu=True)
+    h = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
+    return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)

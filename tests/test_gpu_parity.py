@@ -437,3 +437,27 @@ def test_batch_norm_act_vs_torch(N, C, relu, res):
     assert int(bn_hip.num_batches_tracked) == 1
     if res:
         _close(rd.grad, rr.grad, "dres")
+
+
+@pytest.mark.parametrize("N,O,I", [(4099, 104, 104), (1500, 33, 40), (2048, 256, 256), (1025, 1, 7), (3000, 96, 13)])
+def test_linear_wgrad_mfma_vs_torch(N, O, I):
+    """dW, db of nn.Linear on the fp32 matrix cores (asymmetric data catches a swapped C/D map)."""
+    from kp_gnn_amd.ops_dense import LinearWgrad
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + O)
+    x = torch.randn(N, I, generator=g)
+    w = torch.randn(O, I, generator=g) * 0.1
+    b = torch.randn(O, generator=g)
+    gy = torch.randn(N, O, generator=g) * (1 + torch.arange(O) * 0.01)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (torch.nn.functional.linear(xr, wr, br) * gy).sum().backward()
+    xd, wd, bd = (t.clone().to(dev).requires_grad_(True) for t in (x, w, b))
+    out = LinearWgrad.apply(xd, wd, bd)
+    (out * gy.to(dev)).sum().backward()
+    _close(wd.grad, wr.grad, "dW", rtol=2e-4, atol=2e-5)
+    _close(bd.grad, br.grad, "db", rtol=2e-4, atol=2e-5)
+    _close(xd.grad, xr.grad, "dx", rtol=2e-4, atol=2e-5)
+    # without bias
+    wd2 = w.clone().to(dev).requires_grad_(True)
+    (LinearWgrad.apply(x.to(dev), wd2, None) * gy.to(dev)).sum().backward()
+    _close(wd2.grad, wr.grad, "dW (no bias)", rtol=2e-4, atol=2e-5)
