@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
-from .ops import DictPeripheral, table_gather_sum
+from .ops import DictPeripheral, embedding_rows, table_gather_sum
 from .ops_dense import batch_norm_act
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
@@ -96,6 +96,8 @@ class EmbeddingEncoder(nn.Module):
         self.init_proj.reset_parameters()
 
     def forward(self, data):
+        if data.x.is_cuda and data.x.dtype in (torch.int64, torch.int32):
+            return embedding_rows(self.init_proj.weight, data.x)
         return self.init_proj(data.x)
 
 

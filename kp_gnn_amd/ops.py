@@ -435,3 +435,26 @@ class TableGatherSum(torch.autograd.Function):
 
 def table_gather_sum(table, bias, idx, col_offset):
     return TableGatherSum.apply(table, bias, idx, col_offset)
+
+
+_I16 = "_kpgnn_idx16"
+
+
+def embedding_rows(weight, idx):
+    """weight[idx] for an integer index tensor [M] or [M,1] (the bodies' input embedding, input_encoder.py:21-22)
+    through the gather-sum kernels: unlike the framework's embedding backward (sort + unique_by_key with a host
+    read-back) this is free of host synchronisation, hence hipGraph-capturable.  The int16 copy of the index is
+    cached on the index tensor object."""
+    rec = getattr(idx, _I16, None)
+    if rec is None or rec[0] != idx._version:
+        if weight.shape[0] > 32768:
+            return torch.nn.functional.embedding(idx, weight)
+        i16 = idx.reshape(-1, 1).to(torch.int16).contiguous()
+        off = torch.zeros(1, dtype=torch.int32, device=idx.device)
+        rec = (idx._version, i16, off)
+        try:
+            setattr(idx, _I16, rec)
+        except Exception:  # pragma: no cover
+            pass
+    out = TableGatherSum.apply(weight, None, rec[1], rec[2])
+    return out.view(*idx.shape, weight.shape[1])
