@@ -13,6 +13,7 @@ Follows
     /root/reference/layers/KPGINplus.py:61-88    kpginplus_forward
     /root/reference/layers/KPGCN.py:11-25,80-126 kpgcn_forward, khop_degree
     /root/reference/layers/gine.py:49-59         gine_forward
+    /root/reference/layers/KPGraphSAGE.py:71-98  kpgraphsage_forward
     /root/reference/layers/combine.py:22-27      attention_combine (nn.LSTM written out gate by gate)
     /root/reference/layers/combine.py:43-58      geometric_combine
     /root/reference/run_simulation.py:70-93      kgin_forward (mask-only variant)
@@ -190,6 +191,25 @@ def kpgcn_forward(p, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=Non
     if K > 1:
         x = F.linear(x, p["combine_proj.weight"], p["combine_proj.bias"])
     return x
+
+
+def kpgraphsage_forward(p, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, *, K, combine_kind="geometric"):
+    """layers/KPGraphSAGE.py:71-98 (sum aggregation)."""
+    dk = p["hop_proj"].shape[1] // 2
+    x = x.reshape(-1, K, dk)
+    x = add_path_encoding(p, x, pe_attr, K)
+    e_emb = edge_code_embedding(p, edge_attr, K)
+    x_j = x.index_select(0, edge_index[0])
+    x_n = propagate_sum(x.size(0), edge_index, masked_message(x_j, e_emb, edge_attr))
+    if peripheral_attr is not None:
+        x_n = x_n + peripheral_attr
+    h = torch.cat([x, x_n], dim=-1).permute(1, 0, 2)
+    h = (torch.matmul(h, p["hop_proj"]) + p["hop_bias"].unsqueeze(1)).permute(1, 0, 2)
+    h = F.normalize(F.relu(h), p=2, dim=-1)
+    h = combine(p, h, K, combine_kind)
+    if K > 1:
+        h = F.linear(h, p["combine_proj.weight"], p["combine_proj.bias"])
+    return h
 
 
 def gine_forward(p, x, edge_index, edge_attr, *, training=True):

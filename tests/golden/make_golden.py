@@ -38,6 +38,7 @@ from layers.input_encoder import EmbeddingEncoder  # noqa: E402
 from layers.KPGCN import KPGCNConv  # noqa: E402
 from layers.KPGIN import KPGINConv  # noqa: E402
 from layers.KPGINplus import KPGINPlusConv  # noqa: E402
+from layers.KPGraphSAGE import KPGraphSAGEConv  # noqa: E402
 from layers.layer_utils import make_gnn_layer  # noqa: E402
 from models.GraphRegression import GraphRegression  # noqa: E402
 from models.model_utils import make_GNN  # noqa: E402
@@ -215,6 +216,10 @@ def layer_case(kind, ctor_kw, batch_names, pre, seed, with_periph=True, K_used=N
         layer = KPGCNConv(**ctor_kw)
         D = ctor_kw["output_size"] // K
         xshape = [b.num_nodes, ctor_kw["input_size"]]
+    elif kind == "KPGraphSAGE":
+        layer = KPGraphSAGEConv(**ctor_kw)
+        D = ctor_kw["input_size"] // K
+        xshape = [b.num_nodes, ctor_kw["input_size"]]
     elif kind == "GINE":
         layer = GINEConv(**ctor_kw)
         D = ctor_kw["input_size"]
@@ -327,6 +332,16 @@ def make_layer_goldens(outdir):
         "GINE", dict(input_size=96, output_size=96, eps=0., num_hop1_edge=3, train_eps=False), mols2, "zinc_k16_gd", 31)
     cases["gine_h16_train_eps"] = layer_case(
         "GINE", dict(input_size=16, output_size=24, eps=0.2, num_hop1_edge=3, train_eps=True), mols3, "zinc_k8_spd", 32)
+    # --- KP-GraphSAGE (layers/KPGraphSAGE.py)
+    cases["kpsage_k3_h33_geo"] = layer_case(
+        "KPGraphSAGE", dict(input_size=33, output_size=33, K=3, aggr="add", num_hop1_edge=1, num_pe=10,
+                            combine="geometric"), ["reg3_n20_s0", "two_components"], "tu_k3_spd", 41)
+    cases["kpsage_k8_in104_out40_att"] = layer_case(
+        "KPGraphSAGE", dict(input_size=104, output_size=40, K=8, aggr="add", num_hop1_edge=3, num_pe=50,
+                            combine="attention"), mols2, "zinc_k8_spd", 42)
+    cases["kpsage_k1_h8"] = layer_case(
+        "KPGraphSAGE", dict(input_size=8, output_size=8, K=1, aggr="add", num_hop1_edge=1, num_pe=10),
+        ["path5", "reg3_n20_s0"], "tu_k3_spd", 43, with_periph=False)
     torch.save(cases, os.path.join(outdir, "layers.pt"))
     print(f"layers.pt: {len(cases)} cases")
 

@@ -88,7 +88,8 @@ def _make_layer(case):
     for b in ("train_eps",):
         if b in ctor:
             ctor[b] = bool(ctor[b])
-    cls = {"KPGIN": L.KPGINConv, "KPGINPlus": L.KPGINPlusConv, "KPGCN": L.KPGCNConv, "GINE": L.GINEConv}[case["kind"]]
+    cls = {"KPGIN": L.KPGINConv, "KPGINPlus": L.KPGINPlusConv, "KPGCN": L.KPGCNConv, "GINE": L.GINEConv,
+           "KPGraphSAGE": L.KPGraphSAGEConv}[case["kind"]]
     layer = cls(**ctor)
     missing = layer.load_state_dict(case["state_dict"], strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -461,3 +462,30 @@ def test_linear_wgrad_mfma_vs_torch(N, O, I):
     wd2 = w.clone().to(dev).requires_grad_(True)
     (LinearWgrad.apply(x.to(dev), wd2, None) * gy.to(dev)).sum().backward()
     _close(wd2.grad, wr.grad, "dW (no bias)", rtol=2e-4, atol=2e-5)
+
+
+def test_kgin_simulation_layer_vs_oracle():
+    """run_simulation.py's mask-only KGINConv on 3-regular graphs (config 4 shapes, small n): fwd + grads vs the
+    oracle restatement (parity unpinned by reference execution: run_simulation.py is a script that cannot be
+    imported without running the whole experiment; its building blocks are pinned through the KP-GIN goldens)."""
+    import networkx as nx
+    from kp_gnn_amd import khop_transform as KT
+    from kp_gnn_amd.layers import KGINConv
+    from oracle import kp_layers_oracle as LO
+    dev = _dev()
+    G = nx.random_regular_graph(3, 64, seed=1)
+    ei = np.array(list(G.to_directed().edges), dtype=np.int64).T
+    out = KT.khop_batch([0, 64], [0, ei.shape[1]], ei, None, 5, 10, 1, 1, 1, 1, "spd", num_threads=1)
+    torch.manual_seed(2)
+    layer = KGINConv(16, 5)
+    x = torch.ones(64, 1) + 0.1 * torch.randn(64, 1)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "eps") for k, v in layer.state_dict().items()}
+    ref = LO.kgin_forward(p, x, out["edge_index"], out["edge_attr"], K=5)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    layer = layer.to(dev)
+    got = layer(x.to(dev), out["edge_index"].to(dev), out["edge_attr"].to(dev))
+    (got * w.to(dev)).sum().backward()
+    _close(got, ref, "out")
+    for k, v in layer.named_parameters():
+        _close(v.grad, p[k].grad, "grad " + k, atol=3e-5)

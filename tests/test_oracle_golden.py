@@ -75,6 +75,9 @@ def _run_layer(case):
     elif kind == "KPGCN":
         out = LO.kpgcn_forward(p, x, case["edge_index"], case["edge_attr"], pe, periph, K=K,
                                combine_kind=ctor.get("combine", "geometric"))
+    elif kind == "KPGraphSAGE":
+        out = LO.kpgraphsage_forward(p, x, case["edge_index"], case["edge_attr"], pe, periph, K=K,
+                                     combine_kind=ctor.get("combine", "geometric"))
     elif kind == "GINE":
         out = LO.gine_forward(p, x, case["edge_index"], case["edge_attr"], training=True)
     (out * case["out_weight"]).sum().backward()
@@ -83,7 +86,7 @@ def _run_layer(case):
 
 def test_layer_oracle_matches_reference(golden_dir):
     cases = torch.load(os.path.join(golden_dir, "layers.pt"), weights_only=True)
-    assert len(cases) >= 19
+    assert len(cases) >= 22
     for name, case in cases.items():
         p, x, periph, out = _run_layer(case)
         _close(out.detach(), case["out"], name + ":out")
