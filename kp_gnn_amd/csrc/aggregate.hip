@@ -15,6 +15,7 @@
 // HBM-bound: per launch the algorithmic traffic is x + P + out (+pre) once, ids/codes once, tables once
 // (DESIGN.md "Algorithmic bytes").  The gather re-reads (A*D*4 bytes) are meant to be served by L2:
 // tiles of consecutive nodes (= same graph) are walked per XCD (kpgnn_common.h XcdTileWalk).
+#include <cstdlib>
 #include <initializer_list>
 
 #include "kpgnn_common.h"
@@ -50,8 +51,9 @@ template <int VEC> struct V {
     __device__ __forceinline__ void fma(float s, const V& o) { for (int i = 0; i < VEC; ++i) v[i] = fmaf(s, o.v[i], v[i]); }
 };
 
-__device__ __forceinline__ float gelu_exact(float x) {  // F.gelu(approximate='none')
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+__device__ __forceinline__ float gelu_exact(float x) {  // F.gelu(approximate='none'), erf to 5e-7 abs
+    float e2;
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f, &e2));
 }
 
 struct FwdParams {
@@ -101,81 +103,106 @@ agg_fwd_kernel(const FwdParams p) {
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
     const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
 
+    int last_u = -1;                        // dictionary row held in registers
+    V<VEC> prow = V<VEC>::zero();
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t i = w.cur * NODES + sg;
         if (i >= p.N) continue;             // whole sub-group leaves together
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
-        int beg = rp[0];
-        for (int k = 0; k < p.K; ++k) {
-            const int end = rp[k + 1];
-            const float* xk = p.x + (int64_t)k * p.x_sk + c0;
-            const float* tab = k == 0 ? tab0 : tabk;
-            V<VEC> acc = V<VEC>::zero();
-            float wacc = 0.f;  // GCN: sum of edge weights of the segment (for the constant x-bias term)
-            for (int base = beg; base < end; base += G) {
-                const int idx = base + sl;
-                int myj = 0, myc = 0;
-                if (idx < end) {
-                    myj = p.col[idx];
-                    if (TAB != 0) myc = p.code[idx];
+        V<VEC> acc = V<VEC>::zero();
+        float wacc = 0.f;                   // GCN: sum of edge weights of the segment (constant x-bias term)
+        int seglen = 0;
+        int cur = 0;                        // hop whose segment is being accumulated (sub-group uniform)
+        int myuid = 0;                      // lane k holds uid[i,k] (fetched with the row pointers, off the epilogue path)
+        if (p.uid && G >= 16 && sl < p.K) myuid = p.uid[i * p.uid_stride + sl];
+
+        // epilogue of segment (i, k): peripheral add, activation, (1+eps) x, fused combine / store
+        auto finish = [&](int k) {
+            if (col_ok) {
+                const float* xk = p.x + (int64_t)k * p.x_sk + c0;
+                const float* tab = k == 0 ? tab0 : tabk;
+                V<VEC> v = acc;
+                // constant row added to every x row of hops >= 1: hopk_node_path_emb(pe_attr == 0), KPGIN.py:92-94
+                const bool biased = p.xbias != nullptr && k >= 1;
+                V<VEC> xb = V<VEC>::zero();
+                if (biased) { xb = V<VEC>::load(p.xbias + c0); v.fma(GCN ? wacc : (float)seglen, xb); }
+                if (GCN) {
+                    const float di = p.dis[i * p.K_csr + k];
+                    V<VEC> self = V<VEC>::load(xk + i * p.x_sn);
+                    self.add(xb);
+                    if (TAB != 0) self.add(V<VEC>::load(tab + 1 * D + c0));  // self-loop code 1 (KPGCN.py:87-89)
+                    v.fma(di, self);                                          // last term of the edge list
+                    for (int q = 0; q < VEC; ++q) v.v[q] *= di;
                 }
-                float myw = 1.0f;
-                if (GCN && idx < end) myw = p.dis[(int64_t)myj * p.K_csr + k];
-                const int cnt = min(G, end - base);
-                for (int t = 0; t < cnt; t += 4) {
-                    int j[4], c[4]; float wgt[4]; V<VEC> r[4];
+                if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+                if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
+                if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
+                if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
+                else if (p.uid) {
+                    const int u = (G >= 16 && p.K <= G) ? __shfl(myuid, sg_lane0 + k) : p.uid[i * p.uid_stride + k];
+                    if (u != last_u) { prow = V<VEC>::load(p.ptab + (int64_t)u * D + c0); last_u = u; }  // mostly one row
+                    v.add(prow);
+                }
+                if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
+                if (COMBINE) {
+                    const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
+                    for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
+                } else {
+                    v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
+                }
+            }
+            acc = V<VEC>::zero();
+            wacc = 0.f;
+            seglen = 0;
+        };
+
+        // The node's K segments are one contiguous run of the col/code arrays: walk it in ONE pass (ids fetched
+        // G at a time, rows gathered 4 deep ACROSS hop boundaries) instead of K dependent index->row phases.
+        const int beg = rp[0], end = rp[p.K];
+        for (int base = beg; base < end; base += G) {
+            const int idx = base + sl;
+            int myj = 0, mych = 0;
+            float myw = 1.0f;
+            if (idx < end) {
+                myj = p.col[idx];
+                int hop = 0;
+                for (int k = 1; k < p.K; ++k) hop += (idx >= rp[k]);     // segment of this entry
+                mych = hop << 16;
+                if (TAB != 0) mych |= (int)p.code[idx];
+                if (GCN) myw = p.dis[(int64_t)myj * p.K_csr + hop];
+            }
+            const int cnt = min(G, end - base);
+            for (int t = 0; t < cnt; t += 4) {
+                int j[4], ch[4]; float wgt[4]; V<VEC> r[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
-                        j[u] = __shfl(myj, srcl);
-                        if (TAB != 0) c[u] = __shfl(myc, srcl);
-                        if (GCN) wgt[u] = __shfl(myw, srcl);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int srcl = sg_lane0 + min(t + u, cnt - 1);
+                    j[u] = __shfl(myj, srcl);
+                    ch[u] = __shfl(mych, srcl);
+                    if (GCN) wgt[u] = __shfl(myw, srcl);
+                }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        r[u] = V<VEC>::zero();
-                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(xk + (int64_t)j[u] * p.x_sn);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    r[u] = V<VEC>::zero();
+                    if (t + u < cnt && col_ok)
+                        r[u] = V<VEC>::load(p.x + (int64_t)j[u] * p.x_sn + (int64_t)(ch[u] >> 16) * p.x_sk + c0);
+                }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (t + u < cnt && col_ok) {
-                            if (TAB != 0) r[u].add(V<VEC>::load(tab + c[u] * D + c0));
+                for (int u = 0; u < 4; ++u) {
+                    if (t + u < cnt) {
+                        const int hop = ch[u] >> 16;
+                        while (cur < hop) { finish(cur); ++cur; }
+                        if (col_ok) {
+                            if (TAB != 0) r[u].add(V<VEC>::load((hop == 0 ? tab0 : tabk) + (ch[u] & 0xFFFF) * D + c0));
                             if (GCN) { acc.fma(wgt[u], r[u]); wacc += wgt[u]; } else acc.add(r[u]);
                         }
+                        ++seglen;
                     }
                 }
             }
-            const int seglen = end - beg;
-            beg = end;
-            if (!col_ok) continue;
-            // ---- epilogue for (i,k)
-            V<VEC> v = acc;
-            // constant row added to every x row of hops >= 1: hopk_node_path_emb(pe_attr == 0), KPGIN.py:92-94
-            const bool biased = p.xbias != nullptr && k >= 1;
-            V<VEC> xb = V<VEC>::zero();
-            if (biased) { xb = V<VEC>::load(p.xbias + c0); v.fma(GCN ? wacc : (float)seglen, xb); }
-            if (GCN) {
-                const float di = p.dis[i * p.K_csr + k];
-                V<VEC> self = V<VEC>::load(xk + i * p.x_sn);
-                self.add(xb);
-                if (TAB != 0) self.add(V<VEC>::load(tab + 1 * D + c0));  // self-loop code 1 (KPGCN.py:87-89)
-                v.fma(di, self);                                          // last term of the edge list
-                for (int q = 0; q < VEC; ++q) v.v[q] *= di;
-            }
-            if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
-            if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
-            if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
-            if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
-            else if (p.uid) v.add(V<VEC>::load(p.ptab + (int64_t)p.uid[i * p.uid_stride + k] * D + c0));
-            if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
-            if (COMBINE) {
-                const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
-                for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
-            } else {
-                v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
-            }
         }
+        while (cur < p.K) { finish(cur); ++cur; }
         if (COMBINE && col_ok) hsum.store(p.hout + i * (int64_t)D + c0);
     }
 }
@@ -317,6 +344,7 @@ int pick_group(int lanes_needed) {
 }
 
 unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
+    if (const char* e = getenv("KPGNN_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) blocks_per_cu = v; }
     const int64_t cap = (int64_t)device_facts().cu_count * blocks_per_cu;
     int64_t g = num_tiles < cap ? num_tiles : cap;
     if (g >= kNumXcd) g = g / kNumXcd * kNumXcd;  // XcdTileWalk wants a multiple of 8

@@ -78,8 +78,9 @@ combine_bwd_kernel(const CbParams p) {
             }
             for (int q = 0; q < VEC; ++q) {
                 if (p.mode == KPGNN_MODE_GINPLUS) {
-                    const float cdf = 0.5f * (1.0f + erff(s[q] * 0.70710678118654752440f));
-                    const float pdf = __expf(-0.5f * s[q] * s[q]) * 0.39894228040143267794f;
+                    float e2;  // exp(-s^2/2) comes with the erf approximation
+                    const float cdf = 0.5f * (1.0f + fast_erf(s[q] * 0.70710678118654752440f, &e2));
+                    const float pdf = e2 * 0.39894228040143267794f;
                     a[q] = s[q] * cdf;
                     gg[q] = gvv[q] * (cdf + s[q] * pdf);
                 } else if (p.mode == KPGNN_MODE_GCN) {
