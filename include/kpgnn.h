@@ -78,6 +78,19 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
                     int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                     void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
+/* Component-aligned node tiles for the LDS-staged aggregation kernels.  A "cut" after node i exists when no
+ * active pair connects a node <= i with a node > i (collated batches: every graph boundary is a cut).  Consecutive
+ * components are packed greedily into tiles of at most `node_cap` nodes and `pair_cap` active pairs (all K_csr
+ * hops); a tile therefore only gathers rows of its OWN node range, which a workgroup can stage in LDS once.
+ * Components larger than the caps are chopped into node_cap chunks flagged 1 (their gathers leave the tile: the
+ * kernels then read those rows from global memory).  Outputs (device): tile_start int32[<= N+1] (node offsets,
+ * tile_start[T] = N), tile_flag uint8[<= N], num_tiles int32[1].  Workspace: N int32. */
+int kpgnn_csr_component_tiles(const int32_t* rowptr_dst, const int32_t* col_dst, const int32_t* rowptr_src,
+                              const int32_t* col_src, int64_t N, int32_t K, int32_t node_cap, int32_t pair_cap,
+                              int32_t* tile_start, uint8_t* tile_flag, int32_t* num_tiles,
+                              void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
+size_t kpgnn_csr_component_tiles_workspace_bytes(int64_t N);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
@@ -127,6 +140,12 @@ typedef struct kpgnn_agg_fwd_desc {
     const float* ptab;
     const int32_t* uid;
     int64_t uid_stride;
+    /* Optional component tiles (kpgnn_csr_component_tiles): with them the launch takes the LDS-staged kernel
+     * (rows, ids and row pointers of a tile staged in LDS; HBM sees only the algorithmic bytes) when the
+     * shape qualifies (D % 4 == 0, 16-B aligned operands, not GCN), else the global-gather kernel. */
+    const int32_t* tile_start;
+    const uint8_t* tile_flag;
+    int32_t num_tiles, tile_node_cap, tile_pair_cap;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

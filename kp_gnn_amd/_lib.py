@@ -27,6 +27,8 @@ class AggFwdDesc(ctypes.Structure):
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
+        ("tile_start", c_vp), ("tile_flag", c_vp), ("num_tiles", c_i32), ("tile_node_cap", c_i32),
+        ("tile_pair_cap", c_i32),
     ]
 
 
@@ -112,6 +114,9 @@ SIGNATURES = {
     "kpgnn_csr_build": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_i64,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
                                        c_vp, ctypes.c_size_t, c_vp]),
+    "kpgnn_csr_component_tiles": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                                 c_vp, ctypes.c_size_t, c_vp]),
+    "kpgnn_csr_component_tiles_workspace_bytes": (ctypes.c_size_t, [c_i64]),
     "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
     "kpgnn_table_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 7),

@@ -356,8 +356,7 @@ int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     const unsigned grid = pick_grid(tiles, 8);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)agg_fwd_kernel<VEC, G, GCN, TAB>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB>, lds));
     hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
     return KPGNN_OK;
@@ -378,8 +377,7 @@ int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     const unsigned grid = pick_grid(tiles, 4);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>, lds));
     hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_bwd_kernel");
     return KPGNN_OK;
@@ -409,6 +407,8 @@ int launch_bwd_mode(const BwdParams& p, int tab, size_t lds, hipStream_t s) {
 }  // namespace
 }  // namespace kpgnn
 
+namespace kpgnn { int launch_agg_fwd_lds(const kpgnn_agg_fwd_desc* d, hipStream_t s); }
+
 using namespace kpgnn;
 
 extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream) {
@@ -424,9 +424,16 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(combine ? d->hout != nullptr : d->out != nullptr, "aggregate_fwd: NULL output");
     int tab = 0;
     size_t lds = 0;
-    if (d->use_tables) {
+    if (d->use_tables)
         KPGNN_REQUIRE(d->table0 && d->n_code0 >= 1 && (d->K == 1 || (d->tablek && d->n_codek >= 1)),
                       "aggregate_fwd: missing embedding tables");
+    KPGNN_REQUIRE(d->periph || !d->uid || (d->ptab && d->uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
+    if (d->tile_start && d->tile_flag && d->num_tiles > 0 && d->tile_node_cap > 0 && d->tile_pair_cap > 0 &&
+        !getenv("KPGNN_NO_LDS_AGG")) {
+        const int rc = launch_agg_fwd_lds(d, (hipStream_t)stream);
+        if (rc != KPGNN_ELIMIT) return rc;   // ELIMIT: shape not covered -> global-gather kernel below
+    }
+    if (d->use_tables) {
         KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || (d->n_code0 >= 2 && (d->K == 1 || d->n_codek >= 2)),
                       "aggregate_fwd: GCN needs code row 1 (self loop) in both tables");
         lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));

@@ -146,10 +146,10 @@ template <int VEC, int G>
 int cb_launch(const CbParams& p, int grid, hipStream_t s) {
     const size_t lds = p.slab ? sizeof(float) * (size_t)(kBlock / G) * p.K * p.D : 0;
     if (p.K <= 8) {
-        if (lds > 64 * 1024) KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)combine_bwd_kernel<VEC, G, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, 8>, lds));
         hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, 8>), dim3(grid), dim3(kBlock), lds, s, p);
     } else {
-        if (lds > 64 * 1024) KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)combine_bwd_kernel<VEC, G, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, 16>, lds));
         hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, 16>), dim3(grid), dim3(kBlock), lds, s, p);
     }
     KPGNN_LAUNCH_CHECK("combine_bwd_kernel");

@@ -50,6 +50,9 @@ struct DeviceFacts {
 };
 const DeviceFacts& device_facts();
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a slow host call: do it once per kernel, raising only.
+hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
+
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,

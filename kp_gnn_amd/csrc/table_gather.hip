@@ -110,13 +110,11 @@ int launch(const TgsParams& p, bool bwd, int splits, size_t lds, hipStream_t s) 
     dim3 grid((unsigned)gx, (unsigned)splits);
     if (bwd) {
         if (lds > 64 * 1024)
-            KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)tgs_kernel<VEC, G, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_kernel<VEC, G, true>, lds));
         hipLaunchKernelGGL((tgs_kernel<VEC, G, true>), grid, dim3(kBlock), lds, s, p);
     } else {
         if (lds > 64 * 1024)
-            KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)tgs_kernel<VEC, G, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_kernel<VEC, G, false>, lds));
         hipLaunchKernelGGL((tgs_kernel<VEC, G, false>), grid, dim3(kBlock), lds, s, p);
     }
     KPGNN_LAUNCH_CHECK("tgs_kernel");

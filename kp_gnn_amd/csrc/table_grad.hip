@@ -279,8 +279,8 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = (p.D % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
     if (pl.lds > 64 * 1024) {
-        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)table_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-        KPGNN_HIP_TRY(hipFuncSetAttribute((const void*)table_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<true>, pl.lds));
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<false>, pl.lds));
     }
     if (vec4) hipLaunchKernelGGL(table_grad_kernel<true>, dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
     else hipLaunchKernelGGL(table_grad_kernel<false>, dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);

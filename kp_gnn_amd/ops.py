@@ -38,6 +38,11 @@ class LaunchTimer:
 
 
 _timer = None
+# The LDS-staged forward kernel (aggregate_lds.hip) is opt-in: at K*D ~ 832 floats per node a tile's rows only fit
+# LDS hop by hop, the per-hop barriers then cost more than the dependent global loads they remove (measured
+# 170 us vs 114 us at N = 47k, K = 8, D = 104; profiles/r01/exp_lds_vs_global.log).  KPGNN_LDS_AGG=1 enables it.
+import os as _os
+_no_lds_tiles = _os.environ.get("KPGNN_LDS_AGG", "0") != "1"
 
 
 def set_launch_timer(timer):
@@ -126,6 +131,17 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
+    tiles = None
+    if mode != MODE_GCN and D % 4 == 0 and D <= 256 and N > 0 and not _no_lds_tiles:
+        # LDS-staged kernel: component-aligned tiles of <= 3 nodes per sub-group of a 512-thread workgroup
+        g = 8
+        while g * 4 < D:
+            g <<= 1
+        node_cap = min(48, 3 * (512 // g), (3 * 512 * 4) // D)
+        if node_cap >= 8:
+            tiles = csr.component_tiles(node_cap, 2048)
+            d.tile_start, d.tile_flag, d.num_tiles = tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2]
+            d.tile_node_cap, d.tile_pair_cap = node_cap, 2048
     pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
     d.pre = _ptr(pre)
     if theta is not None:

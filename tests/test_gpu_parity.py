@@ -489,3 +489,83 @@ def test_kgin_simulation_layer_vs_oracle():
     _close(got, ref, "out")
     for k, v in layer.named_parameters():
         _close(v.grad, p[k].grad, "grad " + k, atol=3e-5)
+
+
+def test_component_tiles_partition():
+    """Tiles are contiguous, cover [0,N), respect the caps, and unflagged tiles are closed under the K-hop edges."""
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    b = synthetic_zinc_batch(200, seed0=3, K=8).to(dev)
+    csr = b.build_csr()
+    for node_cap, pair_cap in ((48, 2048), (24, 400), (8, 64)):
+        ts, tf, T = csr.component_tiles(node_cap, pair_cap)
+        ts, tf = ts.cpu().numpy(), tf.cpu().numpy()
+        assert ts[0] == 0 and ts[T] == csr.N and (np.diff(ts) > 0).all()
+        ei = b.edge_index.cpu().numpy()
+        tile_of = np.searchsorted(ts, np.arange(csr.N), side="right") - 1
+        rp = csr.rowptr_dst.cpu().numpy()
+        for t in range(T):
+            n0, n1 = ts[t], ts[t + 1]
+            assert n1 - n0 <= node_cap
+            if not tf[t]:
+                assert rp[n1 * csr.K] - rp[n0 * csr.K] <= pair_cap
+        crossing = tile_of[ei[0]] != tile_of[ei[1]]
+        assert not (crossing & (tf[tile_of[ei[0]]] == 0)).any() and not (crossing & (tf[tile_of[ei[1]]] == 0)).any()
+    assert (csr.component_tiles(48, 2048)[1] == 0).all()       # molecules always fit
+    assert csr.component_tiles(8, 64)[1].any()                  # tiny caps force the spill path
+
+
+def test_lds_forward_equals_global_gather_forward():
+    """The LDS-staged forward kernel (incl. flagged spill tiles) against the global-gather kernel, bitwise-close."""
+    from kp_gnn_amd import _lib, ops
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    saved = ops._no_lds_tiles
+    b = synthetic_zinc_batch(64, seed0=11, K=8).to(dev)
+    csr = b.build_csr()
+    N = b.num_nodes
+    for D, k in ((104, 8), (104, 3), (24, 8), (96, 1), (16, 5)):
+        g = torch.Generator().manual_seed(D + k)
+        x = torch.randn(N, 8, D, generator=g).to(dev)[:, :k]
+        t0, tk = torch.randn(5, D, generator=g).to(dev), torch.randn(52, D, generator=g).to(dev)
+        P = torch.randn(N, 8, D, generator=g).to(dev)[:, :k]
+        theta = torch.softmax(torch.randn(k, D, generator=g), 0).to(dev)
+        uid = torch.randint(0, 9, (N, 8), generator=g).to(torch.int32).to(dev)[:, :k]
+        ptab = torch.randn(9, D, generator=g).to(dev)
+        eps = torch.tensor([0.3], device=dev)
+        xb = torch.randn(D, generator=g).to(dev)
+        cases = [
+            dict(mode=_lib.MODE_GINPLUS, periph=None, theta=theta, ptab=ptab, uid=uid, want_pre=True),
+            dict(mode=_lib.MODE_GINPLUS, periph=P, theta=None, want_pre=True),
+            dict(mode=_lib.MODE_GIN, periph=P, theta=None, eps=eps, xbias=xb, want_pre=False),
+            dict(mode=_lib.MODE_SUM, periph=None, theta=None, tables=False, want_pre=False),
+        ]
+        for c in cases:
+            outs = []
+            for no_lds in (True, False):
+                ops._no_lds_tiles = no_lds
+                tabs = c.get("tables", True)
+                o, pre = ops.aggregate_fwd_raw(csr, k, c["mode"], x, t0 if tabs else None, tk if tabs else None,
+                                               c.get("periph"), c.get("eps"), c.get("theta"), c.get("xbias"),
+                                               c["want_pre"], ptab=c.get("ptab"), uid=c.get("uid"))
+                outs.append((o, pre))
+            ops._no_lds_tiles = saved
+            _close(outs[1][0], outs[0][0], f"out D={D} k={k} mode={c['mode']}", rtol=1e-5, atol=1e-6)
+            if c["want_pre"]:
+                _close(outs[1][1], outs[0][1], "pre", rtol=1e-5, atol=1e-6)
+    # spill path: caps so small that components are chopped (gathers leave the tile)
+    ts, tf, T = csr.component_tiles(8, 64)
+    import ctypes
+    x = torch.randn(N, 8, 104, device=dev)
+    ref, _ = (lambda: (setattr(ops, "_no_lds_tiles", True), ops.aggregate_fwd_raw(csr, 8, _lib.MODE_SUM, x, None, None, None, None, None, None, False))[1])()
+    ops._no_lds_tiles = saved
+    lib = _lib.load()
+    out = torch.empty_like(ref)
+    d = _lib.AggFwdDesc()
+    d.N, d.K, d.D, d.K_csr, d.mode = N, 8, 104, 8, _lib.MODE_SUM
+    d.rowptr, d.col, d.code = csr.rowptr_dst.data_ptr(), csr.col_dst.data_ptr(), csr.code_dst.data_ptr()
+    d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
+    d.out, d.o_sn, d.o_sk = out.data_ptr(), out.stride(0), out.stride(1)
+    d.tile_start, d.tile_flag, d.num_tiles, d.tile_node_cap, d.tile_pair_cap = ts.data_ptr(), tf.data_ptr(), T, 8, 64
+    _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "fwd")
+    _close(out, ref, "spill tiles", rtol=1e-5, atol=1e-6)
