@@ -321,6 +321,38 @@ typedef struct kpgnn_wgrad_desc {
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);
 int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Attention hop-combine (reference layers/combine.py:8-27): a 1-layer bidirectional LSTM with hidden size K
+ * over the K hop slots scores each slot, softmax over slots, weighted sum of the slots:
+ *     score[n,t] = sum_c ( h_fwd[n,t,c] + h_bwd[n,t,c] ),  w = softmax_t(score),  out[n,:] = sum_t w[n,t] x[n,t,:]
+ * The input projection  gin = x W_ih^T + b_ih + b_hh  ([N*K, D] x [D, 8K], both directions side by side) is a plain
+ * GEMM and stays on the matrix-core library; these entry points do the rest:
+ *   fwd: the K-step recurrence, one thread per (node, direction), W_hh wave-uniform, state in registers; then
+ *        softmax + weighted sum.  Saves the gate activations and cell states (5K floats per step) for backward.
+ *   bwd: d(out) -> dw, dx (direct part), softmax backward, BPTT in registers -> dgin [N*K, 8K] and h_prev [N*K,2,K]
+ *        (dW_ih, db, dW_hh are then weight-gradient GEMMs of dgin: kpgnn_linear_wgrad; dx += dgin W_ih).
+ * K <= 16.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_attn_desc {
+    int32_t N, K, D;
+    const float* x; int64_t x_sn, x_sk;     /* device [N,K,D] */
+    const float* gin;                       /* device [N,K,2,4K] contiguous: input projections incl. both biases */
+    const float* whh;                       /* device [2,4K,K] contiguous: weight_hh_l0, weight_hh_l0_reverse */
+    float* acts;                            /* device [2,N,K,5K]: i,f,g,o (activated), c per step (fwd: out, bwd: in) */
+    float* hsum;                            /* device [2,N,K] workspace: sum_c h */
+    float* w;                               /* device [N,K] softmax weights (fwd: out, bwd: in) */
+    float* out;                             /* device [N,D] (fwd) */
+    /* backward only */
+    const float* gout;                      /* device [N,D] */
+    float* dx;                              /* device [N,K,D] contiguous: receives the DIRECT part w[n,t]*gout[n,:] */
+    float* ds;                              /* device [N,K] workspace: d(score) */
+    float* dgin;                            /* device [N,K,2,4K] */
+    float* hprev;                           /* device [N,K,2,K]: h_{t-1} of each step, for dW_hh */
+} kpgnn_attn_desc;
+
+int kpgnn_attn_fwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
+int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

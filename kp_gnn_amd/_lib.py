@@ -96,6 +96,15 @@ class WgradDesc(ctypes.Structure):
     ]
 
 
+class AttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32),
+        ("x", c_vp), ("x_sn", c_i64), ("x_sk", c_i64),
+        ("gin", c_vp), ("whh", c_vp), ("acts", c_vp), ("hsum", c_vp), ("w", c_vp), ("out", c_vp),
+        ("gout", c_vp), ("dx", c_vp), ("ds", c_vp), ("dgin", c_vp), ("hprev", c_vp),
+    ]
+
+
 class TgsDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
@@ -128,6 +137,8 @@ SIGNATURES = {
     "kpgnn_bn_bwd": (ctypes.c_int, [ctypes.POINTER(BnBwdDesc), c_vp]),
     "kpgnn_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
+    "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
+    "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

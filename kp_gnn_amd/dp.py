@@ -18,6 +18,12 @@ def flatten_grads(model):
     return flat
 
 
+def grad_views(model):
+    """(parameters, their .grad views into the flat bucket) in bucket order; flatten_grads must have run."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    return params, [p.grad for p in params]
+
+
 def allreduce_mean(flat, world):
     """Mean of the flat gradient bucket over ranks.  Equal shards per rank => the mean of local-mean-loss
     gradients is the gradient of the global mean loss the reference computes on GPU 0 (train_ZINC.py:36,42)."""

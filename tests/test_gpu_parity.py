@@ -569,3 +569,27 @@ def test_lds_forward_equals_global_gather_forward():
     d.tile_start, d.tile_flag, d.num_tiles, d.tile_node_cap, d.tile_pair_cap = ts.data_ptr(), tf.data_ptr(), T, 8, 64
     _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "fwd")
     _close(out, ref, "spill tiles", rtol=1e-5, atol=1e-6)
+
+
+def test_attention_combine_hip_vs_reference_goldens(golden_dir):
+    """AttentionCombine on the HIP kernels (recurrence, softmax, BPTT, MFMA weight grads) vs the reference's nn.LSTM."""
+    from kp_gnn_amd.layers import AttentionCombine
+    dev = _dev()
+    cases = torch.load(os.path.join(golden_dir, "combine.pt"), weights_only=True)
+    n = 0
+    for name, case in cases.items():
+        if not name.startswith("att"):
+            continue
+        N, K, D = case["x"].shape
+        m = AttentionCombine(D, K)
+        m.load_state_dict(case["state_dict"])
+        m = m.to(dev)
+        x = case["x"].to(dev).requires_grad_(True)
+        out = m(x)
+        (out * case["out_weight"].to(dev)).sum().backward()
+        _close(out, case["out"], name + ":out")
+        _close(x.grad, case["grad_x"], name + ":grad_x")
+        for k, g in case["param_grads"].items():
+            _close(dict(m.named_parameters())[k].grad, g, f"{name}:grad[{k}]", rtol=2e-4, atol=3e-5)
+        n += 1
+    assert n >= 4
