@@ -146,6 +146,10 @@ typedef struct kpgnn_agg_fwd_desc {
     const int32_t* tile_start;
     const uint8_t* tile_flag;
     int32_t num_tiles, tile_node_cap, tile_pair_cap;
+    /* Per-hop inputs (used when x == NULL): hop slot k reads x_slot[k], a [N,D] matrix with row stride x_sn.
+     * GNNPlus stacks the previous layers' states into [N,k,H] with torch.cat every layer (models/GNNs.py:413-418);
+     * with slots the kernel reads the k states where they are and the copy disappears.  K <= 16. */
+    const float* x_slot[16];
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
@@ -168,6 +172,9 @@ typedef struct kpgnn_agg_bwd_desc {
     int64_t gx_sn, gx_sk;
     float* gtable0;             /* device [n_code0, D], accumulated into (NULL: skip table grads) */
     float* gtablek;             /* device [n_codek, D] */
+    /* Per-hop outputs (used when gx == NULL): the gradient of hop slot k goes to gx_slot[k], [N,D] with row
+     * stride gx_sn (the backward of the per-hop inputs above: no [N,k,D] tensor to slice up afterwards). */
+    float* gx_slot[16];
 } kpgnn_agg_bwd_desc;
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);

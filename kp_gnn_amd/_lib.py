@@ -29,6 +29,7 @@ class AggFwdDesc(ctypes.Structure):
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("tile_start", c_vp), ("tile_flag", c_vp), ("num_tiles", c_i32), ("tile_node_cap", c_i32),
         ("tile_pair_cap", c_i32),
+        ("x_slot", c_vp * 16),
     ]
 
 
@@ -41,6 +42,7 @@ class AggBwdDesc(ctypes.Structure):
         ("eps", c_vp),
         ("gx", c_vp), ("gx_sn", c_i64), ("gx_sk", c_i64),
         ("gtable0", c_vp), ("gtablek", c_vp),
+        ("gx_slot", c_vp * 16),
     ]
 
 

@@ -356,9 +356,12 @@ class GNNPlus(_KHopBody):
             if self.virtual_node:
                 h_list[l] = h_list[l] + vn[batch]
             k = min(l + 1, self.K)
-            xs = torch.stack([h_list[l - m] for m in range(k)], dim=1)  # slot m = state of layer l-m
+            slots = [h_list[l - m] for m in range(k)]                  # slot m = state of layer l-m
             pek = pe_attr[:, :k - 1] if pe_attr is not None else None
-            h = self.gnns[l](xs, edge_index, edge_attr[:, :k], pek, periph[:, :k])
+            if hasattr(self.gnns[l], "forward_slots") and slots[0].is_cuda:
+                h = self.gnns[l].forward_slots(slots, edge_index, edge_attr[:, :k], pek, periph[:, :k])
+            else:
+                h = self.gnns[l](torch.stack(slots, dim=1), edge_index, edge_attr[:, :k], pek, periph[:, :k])
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
             h = self.norms[l](h, residual=last_h if fuse_res else None)   # norm (+ residual) in one pass
             if l != self.num_layer - 1:

@@ -73,6 +73,7 @@ struct FwdParams {
     float* hout;
     const float* xbias;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
+    const float* xs[16];        // per-hop inputs (x == NULL)
 };
 
 // TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
@@ -105,104 +106,87 @@ agg_fwd_kernel(const FwdParams p) {
 
     int last_u = -1;                        // dictionary row held in registers
     V<VEC> prow = V<VEC>::zero();
+    // (A variant that walks a node's whole neighbour list in one pass - hop from row-pointer compares - was
+    //  measured slower: 134 us vs 109 us per launch at N = 47k, its 120 VGPRs cost a wave per SIMD.)
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t i = w.cur * NODES + sg;
         if (i >= p.N) continue;             // whole sub-group leaves together
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
-        V<VEC> acc = V<VEC>::zero();
-        float wacc = 0.f;                   // GCN: sum of edge weights of the segment (constant x-bias term)
-        int seglen = 0;
-        int cur = 0;                        // hop whose segment is being accumulated (sub-group uniform)
-        int myuid = 0;                      // lane k holds uid[i,k] (fetched with the row pointers, off the epilogue path)
-        if (p.uid && G >= 16 && sl < p.K) myuid = p.uid[i * p.uid_stride + sl];
-
-        // epilogue of segment (i, k): peripheral add, activation, (1+eps) x, fused combine / store
-        auto finish = [&](int k) {
-            if (col_ok) {
-                const float* xk = p.x + (int64_t)k * p.x_sk + c0;
-                const float* tab = k == 0 ? tab0 : tabk;
-                V<VEC> v = acc;
-                // constant row added to every x row of hops >= 1: hopk_node_path_emb(pe_attr == 0), KPGIN.py:92-94
-                const bool biased = p.xbias != nullptr && k >= 1;
-                V<VEC> xb = V<VEC>::zero();
-                if (biased) { xb = V<VEC>::load(p.xbias + c0); v.fma(GCN ? wacc : (float)seglen, xb); }
-                if (GCN) {
-                    const float di = p.dis[i * p.K_csr + k];
-                    V<VEC> self = V<VEC>::load(xk + i * p.x_sn);
-                    self.add(xb);
-                    if (TAB != 0) self.add(V<VEC>::load(tab + 1 * D + c0));  // self-loop code 1 (KPGCN.py:87-89)
-                    v.fma(di, self);                                          // last term of the edge list
-                    for (int q = 0; q < VEC; ++q) v.v[q] *= di;
+        int beg = rp[0];
+        for (int k = 0; k < p.K; ++k) {
+            const int end = rp[k + 1];
+            const float* xk = (p.x ? p.x + (int64_t)k * p.x_sk : p.xs[k]) + c0;
+            const float* tab = k == 0 ? tab0 : tabk;
+            V<VEC> acc = V<VEC>::zero();
+            float wacc = 0.f;  // GCN: sum of edge weights of the segment (for the constant x-bias term)
+            for (int base = beg; base < end; base += G) {
+                const int idx = base + sl;
+                int myj = 0, myc = 0;
+                if (idx < end) {
+                    myj = p.col[idx];
+                    if (TAB != 0) myc = p.code[idx];
                 }
-                if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
-                if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
-                if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
-                if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
-                else if (p.uid) {
-                    const int u = (G >= 16 && p.K <= G) ? __shfl(myuid, sg_lane0 + k) : p.uid[i * p.uid_stride + k];
-                    if (u != last_u) { prow = V<VEC>::load(p.ptab + (int64_t)u * D + c0); last_u = u; }  // mostly one row
-                    v.add(prow);
-                }
-                if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
-                if (COMBINE) {
-                    const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
-                    for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
-                } else {
-                    v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
-                }
-            }
-            acc = V<VEC>::zero();
-            wacc = 0.f;
-            seglen = 0;
-        };
-
-        // The node's K segments are one contiguous run of the col/code arrays: walk it in ONE pass (ids fetched
-        // G at a time, rows gathered 4 deep ACROSS hop boundaries) instead of K dependent index->row phases.
-        const int beg = rp[0], end = rp[p.K];
-        for (int base = beg; base < end; base += G) {
-            const int idx = base + sl;
-            int myj = 0, mych = 0;
-            float myw = 1.0f;
-            if (idx < end) {
-                myj = p.col[idx];
-                int hop = 0;
-                for (int k = 1; k < p.K; ++k) hop += (idx >= rp[k]);     // segment of this entry
-                mych = hop << 16;
-                if (TAB != 0) mych |= (int)p.code[idx];
-                if (GCN) myw = p.dis[(int64_t)myj * p.K_csr + hop];
-            }
-            const int cnt = min(G, end - base);
-            for (int t = 0; t < cnt; t += 4) {
-                int j[4], ch[4]; float wgt[4]; V<VEC> r[4];
+                float myw = 1.0f;
+                if (GCN && idx < end) myw = p.dis[(int64_t)myj * p.K_csr + k];
+                const int cnt = min(G, end - base);
+                for (int t = 0; t < cnt; t += 4) {
+                    int j[4], c[4]; float wgt[4]; V<VEC> r[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int srcl = sg_lane0 + min(t + u, cnt - 1);
-                    j[u] = __shfl(myj, srcl);
-                    ch[u] = __shfl(mych, srcl);
-                    if (GCN) wgt[u] = __shfl(myw, srcl);
-                }
+                    for (int u = 0; u < 4; ++u) {
+                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
+                        j[u] = __shfl(myj, srcl);
+                        if (TAB != 0) c[u] = __shfl(myc, srcl);
+                        if (GCN) wgt[u] = __shfl(myw, srcl);
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    r[u] = V<VEC>::zero();
-                    if (t + u < cnt && col_ok)
-                        r[u] = V<VEC>::load(p.x + (int64_t)j[u] * p.x_sn + (int64_t)(ch[u] >> 16) * p.x_sk + c0);
-                }
+                    for (int u = 0; u < 4; ++u) {
+                        r[u] = V<VEC>::zero();
+                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(xk + (int64_t)j[u] * p.x_sn);
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (t + u < cnt) {
-                        const int hop = ch[u] >> 16;
-                        while (cur < hop) { finish(cur); ++cur; }
-                        if (col_ok) {
-                            if (TAB != 0) r[u].add(V<VEC>::load((hop == 0 ? tab0 : tabk) + (ch[u] & 0xFFFF) * D + c0));
+                    for (int u = 0; u < 4; ++u) {
+                        if (t + u < cnt && col_ok) {
+                            if (TAB != 0) r[u].add(V<VEC>::load(tab + c[u] * D + c0));
                             if (GCN) { acc.fma(wgt[u], r[u]); wacc += wgt[u]; } else acc.add(r[u]);
                         }
-                        ++seglen;
                     }
                 }
             }
+            const int seglen = end - beg;
+            beg = end;
+            if (!col_ok) continue;
+            // ---- epilogue for (i,k)
+            V<VEC> v = acc;
+            // constant row added to every x row of hops >= 1: hopk_node_path_emb(pe_attr == 0), KPGIN.py:92-94
+            const bool biased = p.xbias != nullptr && k >= 1;
+            V<VEC> xb = V<VEC>::zero();
+            if (biased) { xb = V<VEC>::load(p.xbias + c0); v.fma(GCN ? wacc : (float)seglen, xb); }
+            if (GCN) {
+                const float di = p.dis[i * p.K_csr + k];
+                V<VEC> self = V<VEC>::load(xk + i * p.x_sn);
+                self.add(xb);
+                if (TAB != 0) self.add(V<VEC>::load(tab + 1 * D + c0));  // self-loop code 1 (KPGCN.py:87-89)
+                v.fma(di, self);                                          // last term of the edge list
+                for (int q = 0; q < VEC; ++q) v.v[q] *= di;
+            }
+            if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
+            if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
+            if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
+            else if (p.uid) {
+                const int u = p.uid[i * p.uid_stride + k];
+                if (u != last_u) { prow = V<VEC>::load(p.ptab + (int64_t)u * D + c0); last_u = u; }  // mostly one row
+                v.add(prow);
+            }
+            if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
+            if (COMBINE) {
+                const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
+                for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
+            } else {
+                v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
+            }
         }
-        while (cur < p.K) { finish(cur); ++cur; }
         if (COMBINE && col_ok) hsum.store(p.hout + i * (int64_t)D + c0);
     }
 }
@@ -218,6 +202,7 @@ struct BwdParams {
     float* gx; int64_t gx_sn, gx_sk;
     float* gtable0;
     float* gtablek;
+    float* gxs[16];             // per-hop outputs (gx == NULL)
 };
 
 // TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
@@ -306,7 +291,7 @@ agg_bwd_kernel(const BwdParams p) {
                     for (int q = 0; q < VEC; ++q) atomicAdd(dst + q, self.v[q]);
                 }
             }
-            acc.store(p.gx + j * p.gx_sn + (int64_t)k * p.gx_sk + c0);
+            acc.store((p.gx ? p.gx + (int64_t)k * p.gx_sk : p.gxs[k]) + j * p.gx_sn + c0);
         }
     }
     if (TAB == 1) {
@@ -417,7 +402,11 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
                   d->N, d->K, d->D, d->K_csr);
     if ((int64_t)d->N * d->K_csr >= ((int64_t)1 << 31)) return fail(KPGNN_ELIMIT, "aggregate_fwd: N*K exceeds int32");
     if (d->N == 0) return KPGNN_OK;
-    KPGNN_REQUIRE(d->rowptr && d->x, "aggregate_fwd: NULL rowptr/x");
+    KPGNN_REQUIRE(d->rowptr != nullptr, "aggregate_fwd: NULL rowptr");
+    if (!d->x) {
+        KPGNN_REQUIRE(d->K <= 16, "aggregate_fwd: per-hop inputs need K <= 16");
+        for (int k = 0; k < d->K; ++k) KPGNN_REQUIRE(d->x_slot[k] != nullptr, "aggregate_fwd: NULL x and NULL x_slot[%d]", k);
+    }
     KPGNN_REQUIRE(d->mode >= KPGNN_MODE_GIN && d->mode <= KPGNN_MODE_SUM, "aggregate_fwd: unknown mode %d", d->mode);
     KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || d->dis, "aggregate_fwd: GCN mode needs dis");
     const bool combine = d->theta != nullptr;
@@ -428,7 +417,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->table0 && d->n_code0 >= 1 && (d->K == 1 || (d->tablek && d->n_codek >= 1)),
                       "aggregate_fwd: missing embedding tables");
     KPGNN_REQUIRE(d->periph || !d->uid || (d->ptab && d->uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
-    if (d->tile_start && d->tile_flag && d->num_tiles > 0 && d->tile_node_cap > 0 && d->tile_pair_cap > 0 &&
+    if (d->x && d->tile_start && d->tile_flag && d->num_tiles > 0 && d->tile_node_cap > 0 && d->tile_pair_cap > 0 &&
         !getenv("KPGNN_NO_LDS_AGG")) {
         const int rc = launch_agg_fwd_lds(d, (hipStream_t)stream);
         if (rc != KPGNN_ELIMIT) return rc;   // ELIMIT: shape not covered -> global-gather kernel below
@@ -449,8 +438,13 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     KPGNN_REQUIRE(p.uid == nullptr || (p.ptab != nullptr && p.uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
-    const int vec = pick_vec(d->D, {d->x, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
-                             {d->x_sn, d->x_sk, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
+    const void* slot_align = nullptr;   // the least aligned per-hop input decides the vector width
+    for (int k = 0; k < 16; ++k) {
+        p.xs[k] = (!d->x && k < d->K) ? d->x_slot[k] : nullptr;
+        if (p.xs[k] && (!slot_align || ((uintptr_t)p.xs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.xs[k];
+    }
+    const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
+                             {d->x_sn, d->x ? d->x_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
                               d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_fwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);
@@ -468,7 +462,11 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
                   d->N, d->K, d->D, d->K_csr);
     if ((int64_t)d->N * d->K_csr >= ((int64_t)1 << 31)) return fail(KPGNN_ELIMIT, "aggregate_bwd: N*K exceeds int32");
     if (d->N == 0) return KPGNN_OK;
-    KPGNN_REQUIRE(d->rowptr_src && d->g && d->gx, "aggregate_bwd: NULL rowptr/g/gx");
+    KPGNN_REQUIRE(d->rowptr_src && d->g, "aggregate_bwd: NULL rowptr/g");
+    if (!d->gx) {
+        KPGNN_REQUIRE(d->K <= 16, "aggregate_bwd: per-hop outputs need K <= 16");
+        for (int k = 0; k < d->K; ++k) KPGNN_REQUIRE(d->gx_slot[k] != nullptr, "aggregate_bwd: NULL gx and NULL gx_slot[%d]", k);
+    }
     KPGNN_REQUIRE(d->mode >= KPGNN_MODE_GIN && d->mode <= KPGNN_MODE_SUM, "aggregate_bwd: unknown mode %d", d->mode);
     KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || d->dis, "aggregate_bwd: GCN mode needs dis");
     int tab = 0;
@@ -484,7 +482,12 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
     p.rowptr = d->rowptr_src; p.col = d->col_src; p.code = d->code_src; p.dis = d->dis;
     p.g = d->g; p.g_sn = d->g_sn; p.g_sk = d->g_sk; p.eps = d->eps;
     p.gx = d->gx; p.gx_sn = d->gx_sn; p.gx_sk = d->gx_sk; p.gtable0 = d->gtable0; p.gtablek = d->gtablek;
-    const int vec = pick_vec(d->D, {d->g, d->gx}, {d->g_sn, d->g_sk, d->gx_sn, d->gx_sk});
+    const void* slot_align = nullptr;
+    for (int k = 0; k < 16; ++k) {
+        p.gxs[k] = (!d->gx && k < d->K) ? d->gx_slot[k] : nullptr;
+        if (p.gxs[k] && (!slot_align || ((uintptr_t)p.gxs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.gxs[k];
+    }
+    const int vec = pick_vec(d->D, {d->g, d->gx ? (const void*)d->gx : slot_align}, {d->g_sn, d->g_sk, d->gx_sn, d->gx ? d->gx_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_bwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);
     const int g = pick_group(lanes);

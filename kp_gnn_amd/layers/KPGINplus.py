@@ -36,8 +36,17 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
         if self.K > 1:
             self.combine.reset_parameters()
 
+    def forward_slots(self, h_slots, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
+        """Same as forward(torch.stack(h_slots, 1), ...) without the stacking copy (and without the slicing
+        adds in backward): hop slot m reads h_slots[m] ([N,H]) where it lives.  Extension of the reference API
+        used by kp_gnn_amd.body.GNNPlus; GNNs.py:413-418 builds the stack with torch.cat every layer."""
+        from ..khop_csr import path_encoding_is_zero
+        if self.K > 1 and pe_attr is not None and not path_encoding_is_zero(pe_attr):
+            return self.forward(torch.stack(list(h_slots), dim=1), edge_index, edge_attr, pe_attr, peripheral_attr)
+        return self.forward(list(h_slots), edge_index, edge_attr, pe_attr, peripheral_attr)
+
     def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
-        n = x.size(0)
+        n = x[0].size(0) if isinstance(x, list) else x.size(0)
         csr, k_act = self._csr(edge_index, edge_attr, n)
         x, xbias = self._path_encoding(x, pe_attr)
         t0, tk = self._tables()

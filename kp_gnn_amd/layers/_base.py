@@ -56,7 +56,7 @@ class EdgeCodeTables(object):
         into its epilogue, so no [N,K,D] pass is spent on adding zeros."""
         if self.K == 1 or pe_attr is None:
             return x, None
-        if path_encoding_is_zero(pe_attr):
+        if isinstance(x, list) or path_encoding_is_zero(pe_attr):  # (lists only arrive with all-padding pe_attr)
             return x, self.hopk_node_path_emb.weight[0].detach()
         pe = F.embedding(pe_attr, self.hopk_node_path_emb.weight, padding_idx=0)
         return torch.cat([x[:, :1], x[:, 1:] + pe], dim=1), None

@@ -109,12 +109,18 @@ class DictPeripheral:
         return DictRows.apply(self.table, self.uid)
 
 
-def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None):
-    """Launch kpgnn_aggregate_fwd.  Returns (out or hout, pre or None)."""
+def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None,
+                      xs=None):
+    """Launch kpgnn_aggregate_fwd.  x is [N,k,D], or None with xs = k per-hop [N,D] tensors (row stride shared).
+    Returns (out or hout, pre or None)."""
     lib = _lib.load()
-    N, K, D = x.shape
+    if x is not None:
+        N, K, D = x.shape
+    else:
+        N, D = xs[0].shape
+        K = len(xs)
     assert K == k_act and N == csr.N
-    dev = x.device
+    dev = (x if x is not None else xs[0]).device
     d = _lib.AggFwdDesc()
     d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
     use_tables = table0 is not None
@@ -123,7 +129,13 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     d.n_codek = tablek.shape[0] if (use_tables and tablek is not None) else 0
     d.rowptr, d.col, d.code = csr.rowptr_dst.data_ptr(), csr.col_dst.data_ptr(), csr.code_dst.data_ptr()
     d.dis = csr.gcn_dis().data_ptr() if mode == MODE_GCN else None
-    d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
+    if x is not None:
+        d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
+    else:
+        d.x_sn = xs[0].stride(0)
+        for k, t in enumerate(xs):
+            assert t.shape == (N, D) and t.stride(1) == 1 and t.stride(0) == d.x_sn
+            d.x_slot[k] = t.data_ptr()
     d.table0, d.tablek = _ptr(table0), _ptr(tablek)
     if periph is not None:
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
@@ -132,7 +144,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
     tiles = None
-    if mode != MODE_GCN and D % 4 == 0 and D <= 256 and N > 0 and not _no_lds_tiles:
+    if x is not None and mode != MODE_GCN and D % 4 == 0 and D <= 256 and N > 0 and not _no_lds_tiles:
         # LDS-staged kernel: component-aligned tiles of <= 3 nodes per sub-group of a 512-thread workgroup
         g = 8
         while g * 4 < D:
@@ -154,7 +166,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(x)), "kpgnn_aggregate_fwd")
+        _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(out)), "kpgnn_aggregate_fwd")
         if _timer is not None:
             e1.record()
             n_t = 1 + (periph is not None) + (pre is not None) + (theta is None)  # x, dense P, pre, out
@@ -164,8 +176,9 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     return out, pre
 
 
-def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
-    """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek)."""
+def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False):
+    """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek); with slots=True gx is a list of
+    k contiguous [N,D] tensors (one per hop slot) instead of one [N,k,D] tensor."""
     lib = _lib.load()
     N, K, D = g.shape
     dev = g.device
@@ -177,8 +190,14 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables):
     d.dis = csr.gcn_dis().data_ptr() if mode == MODE_GCN else None
     d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
     d.eps = _ptr(eps)
-    gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
-    d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
+    if slots:
+        gx = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(K)]
+        d.gx_sn = D
+        for k, t in enumerate(gx):
+            d.gx_slot[k] = t.data_ptr()
+    else:
+        gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+        d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
     gt0 = gtk = None
     if want_tables:
         gt0 = torch.zeros((n_code0, D), dtype=torch.float32, device=dev)
@@ -291,9 +310,14 @@ class KHopAggregate(torch.autograd.Function):
     kpgnn_aggregate_bwd (the transposed gather for dL/dx)."""
 
     @staticmethod
-    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid):
-        _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid)
-        x = _last_contig(x.float())
+    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, *xs):
+        _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
+        ctx.n_slots = len(xs)
+        if xs:   # per-hop inputs: k separate [N,D] states instead of one stacked [N,k,D] tensor
+            assert x is None and len(xs) == k_act
+            xs = [t.float().contiguous() for t in xs]
+        else:
+            x = _last_contig(x.float())
         if periph is not None:
             periph = _last_contig(periph.float())
             ptab = uid = None
@@ -307,7 +331,7 @@ class KHopAggregate(torch.autograd.Function):
             ptab = ptab.contiguous()
         need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
         out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre,
-                                     ptab=ptab, uid=uid)
+                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None)
         ctx.csr, ctx.k_act, ctx.mode, ctx.uid = csr, k_act, mode, uid
         ctx.has_tables = table0 is not None
         ctx.n_code0 = table0.shape[0] if table0 is not None else 0
@@ -315,6 +339,8 @@ class KHopAggregate(torch.autograd.Function):
         ctx.has_periph = periph is not None
         ctx.n_dict = ptab.shape[0] if ptab is not None else 0
         eps_needs = eps is not None and eps.requires_grad
+        if eps_needs and xs:
+            x = torch.stack(list(xs), dim=1)
         ctx.save_for_backward(pre, eps, theta, periph if theta is not None else None,
                               x if eps_needs else None, xbias if eps_needs else None,
                               ptab if theta is not None else None)
@@ -361,7 +387,8 @@ class KHopAggregate(torch.autograd.Function):
                     raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
-        gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather)
+        gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
+                                       slots=ctx.n_slots > 0)
         if tables_in_gather:
             gt0, gtk = a0, ak
         geps = None
@@ -372,15 +399,20 @@ class KHopAggregate(torch.autograd.Function):
             geps = (g * xe).sum().reshape(eps.shape)
         # (row 0 of both table grads stays exactly zero: code 0 == "inactive" never enters the CSR, which
         #  is also what nn.Embedding(padding_idx=0) would do)
+        if ctx.n_slots:
+            return (None, gt0, gtk, gperiph, geps, gtheta, None, gdict, None, None, None, None, *gx)
         return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta, None, gdict,
                 None, None, None, None)
 
 
 def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None):
-    """periph: dense [N,k,D] tensor, a DictPeripheral, or None."""
+    """x: [N,k,D] tensor, or a list/tuple of k per-hop [N,D] tensors (no stacking copy).
+    periph: dense [N,k,D] tensor, a DictPeripheral, or None."""
     ptab = uid = None
     if isinstance(periph, DictPeripheral):
         ptab, uid, periph = periph.table, periph.uid, None
+    if isinstance(x, (list, tuple)):
+        return KHopAggregate.apply(None, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, *x)
     return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid)
 
 

@@ -593,3 +593,31 @@ def test_attention_combine_hip_vs_reference_goldens(golden_dir):
             _close(dict(m.named_parameters())[k].grad, g, f"{name}:grad[{k}]", rtol=2e-4, atol=3e-5)
         n += 1
     assert n >= 4
+
+
+def test_per_hop_slot_inputs_equal_stacked_input():
+    """KPGINPlusConv.forward_slots (k separate [N,H] states) == forward(stack): outputs and every gradient."""
+    from kp_gnn_amd.layers import KPGINPlusConv
+    dev = _dev()
+    N, E, K, H = 83, 700, 5, 40
+    ei, ea = _random_khop(N, E, K, seed=41, n0=4, nk=8)
+    ei, ea = ei.to(dev), ea.to(dev)
+    for combine in ("geometric", "attention"):
+        torch.manual_seed(7)
+        layer = KPGINPlusConv(H, H, K, num_hop1_edge=2, num_pe=8, combine=combine).to(dev)
+        hs = [torch.randn(N, H, device=dev) for _ in range(K)]
+        P = torch.randn(N, K, H, device=dev)
+        pe = torch.zeros(N, K - 1, dtype=torch.long, device=dev)
+        w = torch.randn(N, H, device=dev)
+        res = []
+        for use_slots in (False, True):
+            layer.zero_grad()
+            hh = [h.clone().requires_grad_(True) for h in hs]
+            out = layer.forward_slots(hh, ei, ea, pe, P) if use_slots else layer(torch.stack(hh, 1), ei, ea, pe, P)
+            (out * w).sum().backward()
+            res.append((out.detach(), [h.grad for h in hh], {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}))
+        _close(res[1][0], res[0][0], "out")
+        for a, b in zip(res[1][1], res[0][1]):
+            _close(a, b, "grad slot")
+        for k in res[0][2]:
+            _close(res[1][2][k], res[0][2][k], "grad " + k, atol=3e-5)
