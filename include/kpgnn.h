@@ -328,6 +328,22 @@ typedef struct kpgnn_wgrad_desc {
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);
 int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream);
 
+/* y = x W^T (+ b) for tall-skinny x ([N, I], N ~ 50k, I, O <= 256) on the fp32 matrix cores: the nn.Linear
+ * forward of the layers' MLPs, and - called with W^T - their input gradient dx = dy W.  Each wave keeps its
+ * 32 x I strip of W in registers as MFMA A-fragments for the whole launch; 32-row tiles of x are staged in LDS
+ * (padded pitch: conflict-free transposed reads) and stream through v_mfma_f32_32x32x2_f32; x is read once
+ * and y written once (the BLAS library's kernel for this shape takes 24 us, ~3x the HBM time). */
+typedef struct kpgnn_linear_desc {
+    int64_t N;
+    int32_t O, I;
+    const float* x; int64_t x_stride;     /* device [N,I] */
+    const float* w;                       /* device [O,I] contiguous */
+    const float* bias;                    /* device [O] or NULL */
+    float* y; int64_t y_stride;           /* device [N,O] */
+} kpgnn_linear_desc;
+
+int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Attention hop-combine (reference layers/combine.py:8-27): a 1-layer bidirectional LSTM with hidden size K
  * over the K hop slots scores each slot, softmax over slots, weighted sum of the slots:

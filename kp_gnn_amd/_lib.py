@@ -107,6 +107,13 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
+class LinearDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("O", c_i32), ("I", c_i32),
+        ("x", c_vp), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64),
+    ]
+
+
 class TgsDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
@@ -141,6 +148,7 @@ SIGNATURES = {
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
+    "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
 }

@@ -181,22 +181,30 @@ table_grad_kernel(const TgParams p) {
     }
 }
 
-// out[e] = sum_b slab[b][e]   (fixed order: deterministic).  64 outputs x 16 slices of the block range per WG.
+// out[e] = sum_b slab[b][e]   (fixed order: deterministic).  16 outputs x 64 slices of the slab range per WG: each
+// thread adds nslab/64 values (independent loads), the 64 partials of an output meet in LDS.
 __global__ void __launch_bounds__(1024)
 slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, float* __restrict__ out0, int64_t n_out0,
                    float* __restrict__ out1, int64_t n_out1, float* __restrict__ out2) {
-    __shared__ float part[16][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ float part[64][17];
+    const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + o;
     float s = 0.f;
-    if (e < elems)
-        for (int b = slice; b < nslab; b += 16) s += slab[(int64_t)b * elems + e];
-    part[slice][lane] = s;
+    if (e < elems) {
+        int b = slice;
+        for (; b + 192 < nslab; b += 256) {
+            const float v0 = slab[(int64_t)b * elems + e], v1 = slab[(int64_t)(b + 64) * elems + e];
+            const float v2 = slab[(int64_t)(b + 128) * elems + e], v3 = slab[(int64_t)(b + 192) * elems + e];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nslab; b += 64) s += slab[(int64_t)b * elems + e];
+    }
+    part[slice][o] = s;
     __syncthreads();
     if (slice == 0 && e < elems) {
         float tot = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tot += part[q][lane];
+        for (int q = 0; q < 64; ++q) tot += part[q][o];
         if (e < n_out0) out0[e] = tot;
         else if (e < n_out0 + n_out1) out1[e - n_out0] = tot;
         else out2[e - n_out0 - n_out1] = tot;
@@ -208,7 +216,7 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s) {
     if (elems <= 0) return KPGNN_OK;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, s, slab, nslab, elems,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems + 15) / 16)), dim3(1024), 0, s, slab, nslab, elems,
                        out0, n0, out1, n1, out2);
     KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
     return KPGNN_OK;

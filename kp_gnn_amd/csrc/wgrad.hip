@@ -109,3 +109,137 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
     float* db = d->db ? d->db : p.slab + (size_t)kWgradBlocks * (nw + d->O);  // sink behind the slabs
     return slab_reduce(p.slab, grid, nw + d->O, d->dw, nw, db, d->O, nullptr, s);
 }
+
+// ------------------------------------------------------------------------------------------------ y = x W^T + b
+namespace kpgnn {
+namespace {
+
+struct LinParams {
+    int64_t N; int O, I, pitch;
+    const float* x; int64_t xs;
+    const float* w; const float* bias;
+    float* y; int64_t ys;
+};
+
+// KS = number of 2-wide k-steps held in registers (I <= 2*KS)
+template <int KS>
+__global__ void __launch_bounds__(512)
+linear_fwd_kernel(const LinParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xl[];      // [2][32][pitch]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kk = lane >> 5, c = lane & 31;
+    const int nthreads = blockDim.x;
+    const int o = wave * 32 + c;
+    // A fragments: W[o][2*ks + kk]
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int i = 2 * ks + kk;
+        a[ks] = (o < p.O && i < p.I) ? p.w[(int64_t)o * p.I + i] : 0.f;
+    }
+    const int64_t tiles = (p.N + 31) / 32;
+    const int tile_elems = 32 * p.I;
+    // staging map, tile independent: element e = threadIdx.x + q*nthreads of the [32, I] tile -> (row, column).
+    // The first NPRE elements per thread travel through registers (loaded before the MFMA loop of the current tile,
+    // written to the other LDS buffer after it); shapes with more elements per thread stage the rest directly.
+    constexpr int NPRE = 16;
+    int lo[NPRE], go[NPRE], rw[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int e = threadIdx.x + q * nthreads;
+        const int r = e / p.I, i = e - r * p.I;
+        rw[q] = e < tile_elems ? r : 1 << 30;
+        lo[q] = r * p.pitch + i;
+        go[q] = (int)(r * p.xs + i);
+    }
+    float pre[NPRE];
+    auto load_regs = [&](int64_t tl) {
+        const int64_t r0 = tl * 32;
+        const float* base = p.x + r0 * p.xs;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) pre[q] = (rw[q] < 32 && r0 + rw[q] < p.N) ? base[go[q]] : 0.f;
+    };
+    auto store_regs = [&](float* dst) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) if (rw[q] < 32) dst[lo[q]] = pre[q];
+    };
+    auto stage_rest = [&](int64_t tl, float* dst) {
+        const int64_t r0 = tl * 32;
+        for (int e = threadIdx.x + NPRE * nthreads; e < tile_elems; e += nthreads) {
+            const int r = e / p.I, i = e - r * p.I;
+            dst[r * p.pitch + i] = (r0 + r < p.N) ? p.x[(r0 + r) * p.xs + i] : 0.f;
+        }
+    };
+    int64_t tile = blockIdx.x;
+    int buf = 0;
+    if (tile < tiles) { load_regs(tile); store_regs(xl); stage_rest(tile, xl); }
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+        float* cur = xl + buf * 32 * p.pitch;
+        float* nxt = xl + (buf ^ 1) * 32 * p.pitch;
+        const bool more = tile + gridDim.x < tiles;
+        if (more) load_regs(tile + gridDim.x);
+        f32x16 acc;
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const float* brow = cur + c * p.pitch + kk;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float b = (2 * ks + kk < p.I) ? brow[2 * ks] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b, acc, 0, 0, 0);
+        }
+        // C/D map: col = lane & 31 (row r of the tile), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
+        const int64_t r = tile * 32 + c;
+        if (r < p.N) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ob = wave * 32 + 8 * g + 4 * kk;
+                if (ob + 3 < p.O) {
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + ob); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                    *reinterpret_cast<float4*>(p.y + r * p.ys + ob) = v;
+                } else {
+                    for (int q = 0; q < 4; ++q)
+                        if (ob + q < p.O) p.y[r * p.ys + ob + q] = acc[4 * g + q] + (p.bias ? p.bias[ob + q] : 0.f);
+                }
+            }
+        }
+        if (more) { store_regs(nxt); stage_rest(tile + gridDim.x, nxt); }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+}  // namespace
+}  // namespace kpgnn
+
+extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr, "linear_fwd: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_fwd: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
+    if (d->O > 256 || d->I > 256) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d, I=%d exceed 256", d->O, d->I);
+    KPGNN_REQUIRE(d->x && d->w && d->y && d->x_stride >= d->I && d->y_stride >= d->O, "linear_fwd: bad pointers/strides");
+    if ((d->y_stride % 4) != 0 || (((uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
+        return fail(KPGNN_ELIMIT, "linear_fwd: y / bias must be 16-B aligned with y_stride %% 4 == 0");
+    LinParams p;
+    p.N = d->N; p.O = d->O; p.I = d->I; p.pitch = d->I | 1;   // odd pitch: conflict-free column reads
+    p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
+    const int waves = (d->O + 31) / 32;
+    const size_t lds = sizeof(float) * 2 * 32 * (size_t)p.pitch;
+    const int64_t tiles = (d->N + 31) / 32;
+    int64_t grid = (int64_t)device_facts().cu_count * 4;
+    if (grid > tiles) grid = tiles;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 blk(waves * 64);
+    const int ks = (d->I + 1) / 2;
+#define KP_LIN(KSV) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV>, lds)); \
+                         hipLaunchKernelGGL(linear_fwd_kernel<KSV>, dim3((unsigned)grid), blk, lds, s, p); } while (0)
+    if (ks <= 8) KP_LIN(8);
+    else if (ks <= 16) KP_LIN(16);
+    else if (ks <= 32) KP_LIN(32);
+    else if (ks <= 52) KP_LIN(52);
+    else if (ks <= 64) KP_LIN(64);
+    else if (ks <= 96) KP_LIN(96);
+    else KP_LIN(128);
+#undef KP_LIN
+    KPGNN_LAUNCH_CHECK("linear_fwd_kernel");
+    return KPGNN_OK;
+}

@@ -63,6 +63,34 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None
 
 
+import os as _os
+# kpgnn_linear_fwd (fp32-MFMA streaming y = x W^T) is opt-in: measured 43 us per [47k,104]x[104,104] launch against
+# 24 us for the BLAS library's kernel (profiles/r01): the one-accumulator MFMA chain waits on its LDS operand
+# reads.  The weight-gradient kernel (34 us vs the library's 139 us) is always on.
+_USE_MFMA_LINEAR = _os.environ.get("KPGNN_MFMA_LINEAR", "0") == "1"
+
+
+def _mfma_linear(x, w, bias):
+    """y = x w^T + bias on kpgnn_linear_fwd (w: [O,I] contiguous).  Returns None when the shape is not covered."""
+    if not _USE_MFMA_LINEAR:
+        return None
+    lib = _lib.load()
+    N, I = x.shape
+    O = w.shape[0]
+    if O % 4 != 0 or O > 256 or I > 256:
+        return None
+    y = torch.empty((N, O), dtype=torch.float32, device=x.device)
+    d = _lib.LinearDesc()
+    d.N, d.O, d.I = N, O, I
+    d.x, d.x_stride, d.w, d.bias, d.y, d.y_stride = x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), y.stride(0)
+    with torch.cuda.device(x.device):
+        rc = lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(x))
+    if rc == -3:
+        return None
+    _lib.check(rc, "kpgnn_linear_fwd")
+    return y
+
+
 class LinearWgrad(torch.autograd.Function):
     """y = x W^T + b with the GEMMs y and dx on the BLAS library and (dW, db) on the fp32-MFMA streaming
     kernel kpgnn_linear_wgrad (the library's choice for that K = N reduction runs at ~7 TFLOP/s)."""
@@ -71,7 +99,9 @@ class LinearWgrad(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        xc = x if x.stride(-1) == 1 else x.contiguous()
+        y = _mfma_linear(xc, weight.contiguous(), bias)
+        return y if y is not None else F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
@@ -82,7 +112,11 @@ class LinearWgrad(torch.autograd.Function):
         N, O = dy.shape
         I = x.shape[1]
         dev = dy.device
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _mfma_linear(dy, weight.t().contiguous(), None)   # dx = dy W  ==  dy (W^T)^T
+            if dx is None:
+                dx = dy @ weight
         dw = torch.empty((O, I), dtype=torch.float32, device=dev)
         db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
         nb = lib.kpgnn_wgrad_workspace_bytes(O, I)

@@ -621,3 +621,20 @@ def test_per_hop_slot_inputs_equal_stacked_input():
             _close(a, b, "grad slot")
         for k in res[0][2]:
             _close(res[1][2][k], res[0][2][k], "grad " + k, atol=3e-5)
+
+
+@pytest.mark.parametrize("N,O,I", [(4099, 104, 104), (1500, 64, 104), (33, 8, 13), (2048, 256, 256)])
+def test_mfma_linear_forward_kernel(N, O, I):
+    """kpgnn_linear_fwd (opt-in path): y = x W^T + b on the fp32 matrix cores vs torch."""
+    from kp_gnn_amd import ops_dense
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + O + I)
+    x, w, b = torch.randn(N, I, generator=g), torch.randn(O, I, generator=g) * 0.1, torch.randn(O, generator=g)
+    saved = ops_dense._USE_MFMA_LINEAR
+    ops_dense._USE_MFMA_LINEAR = True
+    try:
+        y = ops_dense._mfma_linear(x.to(dev), w.to(dev), b.to(dev))
+    finally:
+        ops_dense._USE_MFMA_LINEAR = saved
+    assert y is not None
+    _close(y, torch.nn.functional.linear(x, w, b), "y", rtol=2e-4, atol=2e-5)
