@@ -207,6 +207,15 @@ typedef struct kpgnn_table_grad_desc {
     float* gdict;               /* device [n_dict, D] */
     void* workspace;            /* device, >= kpgnn_table_grad_workspace_bytes(...) */
     size_t workspace_bytes;
+    /* Optional fused backward pre-pass (fuse_pre != NULL; needs theta, gh; D % 4 == 0, D <= 128, K <= 8): g is not
+     * read but COMPUTED tile by tile as theta[k,:]*gh[i,:]*act'(S[i,k,:]) from S = fuse_pre (kpgnn_combine_bwd's
+     * arithmetic, act by fuse_mode), written to fuse_g for kpgnn_aggregate_bwd, and, when gtheta != NULL, the
+     * theta gradient sum_i gh*(act(S)+P) (P from the dictionary fuse_ptab/uid, or 0) is reduced alongside. */
+    const float* fuse_pre;      /* device [N,K,D] contiguous */
+    float* fuse_g;              /* device [N,K,D] contiguous (output) */
+    const float* fuse_ptab;     /* device [n_dict, D] or NULL */
+    float* gtheta;              /* device [K, D] (output) or NULL */
+    int32_t fuse_mode;          /* KPGNN_MODE_* */
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,

@@ -55,6 +55,7 @@ class TableGradDesc(ctypes.Structure):
         ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp),
         ("gtable0", c_vp), ("gtablek", c_vp), ("gdict", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("fuse_pre", c_vp), ("fuse_g", c_vp), ("fuse_ptab", c_vp), ("gtheta", c_vp), ("fuse_mode", c_i32),
     ]
 
 

@@ -56,7 +56,7 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
-                float* out2, hipStream_t s);
+                float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr);
 
 // erf(z) by Abramowitz-Stegun 7.1.26 (max abs error 5.4e-7 in fp32 over [-6,6]; exact +-1 beyond): ~14 VALU ops
 // against ~30 for libm's erff, which made the GELU epilogue VALU-bound (28 us of a 160 us launch).  Also

@@ -1,6 +1,7 @@
 """Autograd operators over the C ABI (include/kpgnn.h).  Host-side plumbing only: tensors in, pointers
 and strides out; every arithmetic step of the K-hop aggregation runs in the HIP kernels."""
 import ctypes
+import os as _os
 
 import torch
 
@@ -38,10 +39,13 @@ class LaunchTimer:
 
 
 _timer = None
+# Fused backward pre-pass (g, theta grad, table grads, dictionary grads in ONE launch of table_grad_kernel) is opt-in:
+# the 512-thread tile kernel does the erf arithmetic at lower occupancy than the streaming combine_bwd kernel and the
+# step came out 2 % slower (8.89 vs 8.69 ms at B = 2048).  KPGNN_FUSED_BWD=1 enables it; both paths are parity-tested.
+_fused_bwd = _os.environ.get("KPGNN_FUSED_BWD", "0") == "1"
 # The LDS-staged forward kernel (aggregate_lds.hip) is opt-in: at K*D ~ 832 floats per node a tile's rows only fit
 # LDS hop by hop, the per-hop barriers then cost more than the dependent global loads they remove (measured
 # 170 us vs 114 us at N = 47k, K = 8, D = 104; profiles/r01/exp_lds_vs_global.log).  KPGNN_LDS_AGG=1 enables it.
-import os as _os
 _no_lds_tiles = _os.environ.get("KPGNN_LDS_AGG", "0") != "1"
 
 
@@ -217,14 +221,24 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     return gx, gt0, gtk
 
 
-def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None):
+def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None,
+                   fuse_pre=None, fuse_mode=MODE_SUM, fuse_ptab=None, want_gtheta=False):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
-    Returns (gtable0, gtablek, gdict), or None when the tables do not fit the LDS-resident kernel."""
+    With fuse_pre (= S saved by the forward) g is None: the kernel computes g = theta*gh*act'(S) itself, returns it,
+    and can reduce the theta gradient on the way.
+    Returns (gtable0, gtablek, gdict[, g, gtheta]), or None when the shape does not fit the LDS-resident kernel."""
     lib = _lib.load()
-    g = g.contiguous()
-    N, K, D = g.shape
-    dev = g.device
+    fused = fuse_pre is not None
+    if fused:
+        N, K, D = fuse_pre.shape
+        if D % 4 != 0 or D > 128 or K > 8:
+            return None
+        dev = fuse_pre.device
+    else:
+        g = g.contiguous()
+        N, K, D = g.shape
+        dev = g.device
     n0 = n_code0 if edges else 0
     nk = n_codek if (edges and K > 1) else 0
     ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n0, 1) if edges else 0, nk, n_dict)
@@ -236,7 +250,19 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
     if edges:
         d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
-    d.g, d.g_sn, d.g_sk = g.data_ptr(), K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
+    gth = None
+    if fused:
+        g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+        d.fuse_pre, d.fuse_g, d.fuse_mode, d.fuse_ptab = fuse_pre.data_ptr(), g.data_ptr(), fuse_mode, _ptr(fuse_ptab)
+        d.theta, d.gh = theta.data_ptr(), gh.data_ptr()
+        if uid is not None:
+            d.uid, d.uid_stride = uid.data_ptr(), uid.stride(0)
+        if want_gtheta:
+            gth = torch.empty((K, D), dtype=torch.float32, device=dev)
+            d.gtheta = gth.data_ptr()
+    else:
+        d.g = g.data_ptr()
+    d.g_sn, d.g_sk = K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
     gt0 = gtk = gd = None
     if edges:
         gt0 = torch.empty((n0, D), dtype=torch.float32, device=dev)
@@ -255,8 +281,12 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(g)), "kpgnn_table_grad")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("table_grad", 4 * N * K * D + (4 * csr.active_pairs(K) if edges else 0)
-                                   + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0), e0, e1))
+            _timer.records.append(("table_grad_fused" if fused else "table_grad",
+                                   4 * N * K * D * (2 if fused else 1) + (4 * csr.active_pairs(K) if edges else 0)
+                                   + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0)
+                                   + (4 * N * D if fused else 0), e0, e1))
+    if fused:
+        return gt0, gtk, gd, g, gth
     return gt0, gtk, gd
 
 
@@ -356,6 +386,22 @@ class KHopAggregate(torch.autograd.Function):
         want_gdict = ctx.n_dict > 0 and ctx.needs_input_grad[7]
         gtheta = gperiph = gdict = None
         gout = gout.contiguous() if fused else _last_contig(gout)
+        want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        # --- fused backward pre-pass: one kernel computes g, the theta gradient, the edge-code table gradients
+        #     and the dictionary gradient (fused combine, P absent or in dictionary form, not GCN)
+        if fused and mode != MODE_GCN and not ctx.has_periph and _fused_bwd:
+            res = table_grad_raw(csr, None, ctx.n_code0, ctx.n_codek, edges=want_tables,
+                                 uid=uid if ctx.n_dict > 0 else None, n_dict=ctx.n_dict if want_gdict else 0,
+                                 theta=theta, gh=gout, fuse_pre=pre, fuse_mode=mode, fuse_ptab=ptab,
+                                 want_gtheta=ctx.needs_input_grad[5])
+            if res is not None:
+                gt0, gtk, gdict, g, gtheta = res
+                gx, _, _ = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, False,
+                                             slots=ctx.n_slots > 0)
+                if ctx.n_slots:
+                    return (None, gt0, gtk, None, None, gtheta, None, gdict, None, None, None, None, *gx)
+                return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, None, None, gtheta, None, gdict,
+                        None, None, None, None)
         if fused or need_act:
             g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
                                             want_gtheta=fused and ctx.needs_input_grad[5],
@@ -365,7 +411,6 @@ class KHopAggregate(torch.autograd.Function):
             g = gout
             gperiph = gout if want_gperiph else None
         # --- table gradients (edge codes + peripheral dictionary), column-private kernel
-        want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
         tables_in_gather = False
         if want_tables or want_gdict:

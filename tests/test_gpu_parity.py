@@ -638,3 +638,41 @@ def test_mfma_linear_forward_kernel(N, O, I):
         ops_dense._USE_MFMA_LINEAR = saved
     assert y is not None
     _close(y, torch.nn.functional.linear(x, w, b), "y", rtol=2e-4, atol=2e-5)
+
+
+def test_fused_backward_prepass_equals_two_kernel_path():
+    """kpgnn_table_grad with fuse_pre (g, theta grad, table grads, dictionary grads in one launch) == combine_bwd +
+    table_grad, on KP-GIN+ layers with a dictionary P (stacked and slot inputs)."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.layers import KPGINPlusConv
+    from kp_gnn_amd.ops import DictPeripheral
+    dev = _dev()
+    N, E, K, H = 91, 800, 6, 104
+    ei, ea = _random_khop(N, E, K, seed=51, n0=4, nk=8)
+    ei, ea = ei.to(dev), ea.to(dev)
+    torch.manual_seed(9)
+    layer = KPGINPlusConv(H, H, K, num_hop1_edge=2, num_pe=8, combine="geometric").to(dev)
+    with torch.no_grad():
+        layer.combine.alphas.copy_(torch.randn(H) * 0.5)
+    table = torch.randn(5, H, device=dev)
+    uid = torch.randint(0, 5, (N, K), device=dev, dtype=torch.int32)
+    hs = [torch.randn(N, H, device=dev) for _ in range(K)]
+    w = torch.randn(N, H, device=dev)
+    res = []
+    saved = ops._fused_bwd
+    try:
+        for fused in (False, True):
+            ops._fused_bwd = fused
+            layer.zero_grad()
+            t = table.clone().requires_grad_(True)
+            hh = [h.clone().requires_grad_(True) for h in hs]
+            out = layer.forward_slots(hh, ei, ea, None, DictPeripheral(t, uid))
+            (out * w).sum().backward()
+            res.append(([h.grad for h in hh], t.grad, {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}))
+    finally:
+        ops._fused_bwd = saved
+    for a, b in zip(res[1][0], res[0][0]):
+        _close(a, b, "grad slot", rtol=1e-5, atol=2e-6)
+    _close(res[1][1], res[0][1], "grad dict table", atol=3e-5)
+    for k in res[0][2]:
+        _close(res[1][2][k], res[0][2][k], "grad " + k, atol=3e-5)
