@@ -13,8 +13,9 @@ import torch.nn.functional as F
 
 from .._lib import MODE_GIN
 from ..ops import khop_aggregate
+from ..ops_dense import hop_mlp, hop_mlp_supported
 from ._base import EdgeCodeTables, KHopMessagePassing
-from .combine import make_combine
+from .combine import GeometricCombine, make_combine
 
 
 class KPGINConv(KHopMessagePassing, EdgeCodeTables):
@@ -44,6 +45,7 @@ class KPGINConv(KHopMessagePassing, EdgeCodeTables):
         else:
             self.combine = torch.squeeze
             self.combine_proj = nn.Identity()
+        self._fused_mlp = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -66,7 +68,14 @@ class KPGINConv(KHopMessagePassing, EdgeCodeTables):
         t0, tk = self._tables()
         s = khop_aggregate(x, csr, k_act, MODE_GIN, table0=t0, tablek=tk, periph=peripheral_attr, eps=self.eps,
                            xbias=xbias)                                  # N,K,dk = x_n + P + (1+eps) x
-        h = s.transpose(0, 1)                                           # K,N,dk
+        if self._fused_mlp is None:
+            self._fused_mlp = hop_mlp_supported(self.K, self.input_dk, self.output_dk)
+        if self._fused_mlp:       # per-hop MLP (:106-109) and the geometric combine in one launch per direction
+            if isinstance(self.combine, GeometricCombine):
+                return self.combine_proj(hop_mlp(s, self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2,
+                                                 theta=self.combine.theta()))
+            return self.combine_proj(self.combine(hop_mlp(s, self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2)))
+        h = s.transpose(0, 1)                                           # K,N,dk  (hops wider than 32: BLAS)
         h = F.relu(torch.baddbmm(self.hop_bias1.unsqueeze(1), h, self.hop_proj1))
         h = F.relu(torch.baddbmm(self.hop_bias2.unsqueeze(1), h, self.hop_proj2))
         return self.combine_proj(self.combine(h.transpose(0, 1)))

@@ -162,3 +162,65 @@ def mlp_linear_bn_relu_x2(mlp, h):
     the two GEMMs go to hipBLASLt, each BatchNorm+ReLU pair is one fused stats/apply on the HIP kernels."""
     h = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
     return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)
+
+
+# ------------------------------------------------------------------------------- KP-GIN per-hop MLP (+ geometric combine)
+class HopMlp(torch.autograd.Function):
+    """relu(relu(s W1 + b1) W2 + b2) per hop (+ sum_k theta_k * .), one HIP launch per direction (hop_mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, s, w1, b1, w2, b2, theta):
+        lib = _lib.load()
+        s = s.contiguous()
+        N, K, DI = s.shape
+        DO = w1.shape[2]
+        dev = s.device
+        w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        theta = theta.contiguous() if theta is not None else None
+        h = torch.empty((2, N, K, DO), dtype=torch.float32, device=dev)
+        out = torch.empty((N, DO), dtype=torch.float32, device=dev) if theta is not None else None
+        d = _lib.HopMlpDesc()
+        d.N, d.K, d.DI, d.DO = N, K, DI, DO
+        d.s, d.w1, d.b1, d.w2, d.b2, d.theta = s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(theta)
+        d.h1, d.h2, d.out = h[0].data_ptr(), h[1].data_ptr(), _ptr(out)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_hop_mlp_fwd(ctypes.byref(d), _stream(s)), "kpgnn_hop_mlp_fwd")
+        ctx.save_for_backward(s, w1, b1, w2, b2, theta, h)
+        return out if theta is not None else h[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        s, w1, b1, w2, b2, theta, h = ctx.saved_tensors
+        lib = _lib.load()
+        N, K, DI = s.shape
+        DO = w1.shape[2]
+        dev = s.device
+        gout = gout.contiguous()
+        gs = torch.empty((N, K, DI), dtype=torch.float32, device=dev)
+        sizes = [K * DI * DO, K * DO, K * DO * DO, K * DO] + ([K * DO] if theta is not None else [])
+        gflat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        ws_bytes = int(lib.kpgnn_hop_mlp_workspace_bytes(max(N, 1), K, DI, DO))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        d = _lib.HopMlpDesc()
+        d.N, d.K, d.DI, d.DO = N, K, DI, DO
+        d.s, d.w1, d.b1, d.w2, d.b2, d.theta = s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(theta)
+        d.h1, d.h2 = h[0].data_ptr(), h[1].data_ptr()
+        d.gout, d.gs, d.gflat = gout.data_ptr(), gs.data_ptr(), gflat.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_hop_mlp_bwd(ctypes.byref(d), _stream(s)), "kpgnn_hop_mlp_bwd")
+        parts = torch.split(gflat, sizes)
+        gth = parts[4].view(K, DO) if theta is not None else None
+        return gs, parts[0].view(K, DI, DO), parts[1].view(K, DO), parts[2].view(K, DO, DO), parts[3].view(K, DO), gth
+
+
+def hop_mlp_supported(K, DI, DO):
+    """Whether kpgnn_hop_mlp_* covers the shape (wider hops keep the batched-matmul path)."""
+    return int(_lib.load().kpgnn_hop_mlp_workspace_bytes(1, K, DI, DO)) > 0
+
+
+def hop_mlp(s, w1, b1, w2, b2, theta=None):
+    """s [N,K,DI] -> [N,K,DO] (theta None) or [N,DO] = sum_k theta[k] * h2[:,k] (reference KPGIN.py:106-112)."""
+    if not s.is_cuda:
+        raise _lib.KpgnnError("hop_mlp needs device tensors: there is no CPU path")
+    return HopMlp.apply(s, w1, b1, w2, b2, theta)
