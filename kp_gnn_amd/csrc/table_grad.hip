@@ -36,6 +36,7 @@ struct TgParams {
     float* slab;          // [gridDim.x][n0 + nk + U (+ K)][D]
     // fused backward pre-pass (FUSE): g is COMPUTED here from S = pre, gh and theta and written out
     const float* pre; const float* ptab; float* gout; int mode, want_gth;
+    int dbg;              // KPGNN_TG_DEBUG ablation bits (experiments only): 1 skip pair walk, 2 skip dictionary, 4 skip tile copy
 };
 
 // g must be contiguous [N,K,D]: a tile of NT nodes is then one contiguous run of NT*K*D floats, copied to
@@ -51,7 +52,7 @@ template <bool VEC4, bool FUSE>
 __global__ void __launch_bounds__(kThreadsTG)
 table_grad_kernel(const TgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int grp = threadIdx.x / kCols;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kCols);   // wave-uniform: keeps the walk in SALU control flow
     const int t = threadIdx.x % kCols;
     const int lane = t & 63;
     const int d = blockIdx.y * kCols + t;
@@ -161,6 +162,7 @@ table_grad_kernel(const TgParams p) {
                 }
             }
             if (tl + gridDim.x < num_tiles) fuse_prefetch(tl + gridDim.x);
+        } else if (p.dbg & 4) {
         } else if (VEC4) {
             // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
@@ -198,28 +200,33 @@ table_grad_kernel(const TgParams p) {
         //      coalesced load (lane l holds entry l) and broadcasts them with v_readlane (SGPR, no LDS, no
         //      scalar-cache misses); the LDS tile reads of 8 entries are issued back to back before the
         //      (sequential, register-only) run accumulation.  The next chunk is fetched while this one is walked.
+        if (p.dbg & 1) end = beg;
         for (int b0 = beg; b0 < end; b0 += 64) {
             const uint32_t mine = nxt;
             if (b0 + 64 < end) nxt = (b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu;
             const int cnt = min(64, end - b0);
+            // every lane decodes ITS entry once (VALU, 64 entries per instruction); the per-entry scalar work is
+            // then two v_readlane, one compare and the add
+            const int vhop = mine & 0xFFF;
+            const bool vok = vhop < p.K;
+            const int voff = vok ? ((int)((mine >> 12) & 7) * p.K + vhop) * D : 0;
+            const int vcc = (int)(mine >> 15);                             // table<<16 | code
+            const int vrow = vok ? ((vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc) : -1;
             for (int e0 = 0; e0 < cnt; e0 += 8) {
-                uint32_t en[8]; float val[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) en[u] = (uint32_t)__builtin_amdgcn_readlane((int)mine, e0 + u);
+                int off[8], row[8]; float val[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int hop = en[u] & 0xFFF;
-                    const int nit = (en[u] >> 12) & 7;
-                    val[u] = tile[(hop < p.K ? (nit * p.K + hop) : 0) * D + dc];
+                    off[u] = __builtin_amdgcn_readlane(voff, e0 + u);
+                    row[u] = __builtin_amdgcn_readlane(vrow, e0 + u);
                 }
 #pragma unroll
+                for (int u = 0; u < 8; ++u) val[u] = tile[off[u] + dc];
+#pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if ((int)(en[u] & 0xFFF) < p.K) {
-                        const int cc = (int)(en[u] >> 15);                 // table<<16 | code
-                        const int row = (cc >> 16) ? p.n0 + (cc & 0xFFFF) : cc;
-                        if (row != cur) {                                  // wave-uniform
+                    if (row[u] >= 0) {
+                        if (row[u] != cur) {                               // wave-uniform
                             if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
-                            cur = row;
+                            cur = row[u];
                             run = 0.f;
                         }
                         run += val[u];
@@ -229,7 +236,7 @@ table_grad_kernel(const TgParams p) {
         }
         // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register;
         //      theta / gh sit in registers, the (wave-uniform) uids of a node are fetched together
-        if (p.U > 0) {
+        if (p.U > 0 && !(p.dbg & 2)) {
             const int64_t node0 = tl * p.NT;
             for (int n = grp; n < p.NT && node0 + n < p.N; n += kGroups) {
                 const float ghv = ghs[n * kCols + t];
@@ -376,6 +383,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     p.pre = d->fuse_pre; p.ptab = d->fuse_ptab; p.gout = d->fuse_g; p.mode = d->fuse_mode; p.want_gth = (fuse && d->gtheta) ? 1 : 0;
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
+    { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     Plan pl;
     int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl, p.want_gth ? p.K : 0);
     if (rc != KPGNN_OK) return rc;
@@ -383,7 +391,8 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     p.slab = (float*)d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    const bool vec4 = (p.D % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
+    // the tile copy is flat: 16-B loads only need every node's K*D floats to be a multiple of 4
+    const bool vec4 = (((int64_t)p.K * p.D) % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
     if (fuse) {
         KPGNN_REQUIRE((((uintptr_t)p.pre | (uintptr_t)p.gout | (uintptr_t)p.gh | (uintptr_t)p.theta | (uintptr_t)p.ptab) & 15) == 0,
                       "table_grad: fused pre-pass operands must be 16-B aligned");
