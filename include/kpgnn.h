@@ -386,37 +386,42 @@ int kpgnn_attn_fwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
 int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * KP-GIN per-hop MLP + geometric hop-combine (reference layers/KPGIN.py:106-112, combine.py:52-58):
+ * KP-GIN per-hop MLP + geometric hop-combine + combine_proj (reference layers/KPGIN.py:106-112, combine.py:52-58):
  *     h1[n,k,:] = relu( s[n,k,:] W1[k] + b1[k] )      h2[n,k,:] = relu( h1[n,k,:] W2[k] + b2[k] )
- *     out[n,:]  = sum_k theta[k,:] * h2[n,k,:]        (only when theta != NULL; otherwise h2 is the result)
+ *     comb[n,:] = sum_k theta[k,:] * h2[n,k,:]        (only with theta; otherwise h2 [N,K,DO] is the result)
+ *     out[n,:]  = comb[n,:] Wc^T + bc                 (only with wc: H outputs; otherwise comb [N,DO] is the result)
  * The reference runs this as two batched matmuls over [K, N, dk] with dk = hidden/K (13 for ZINC, 20 for QM9,
- * 6 for K=16) - far too narrow for a BLAS tile.  Here a block stages a 64-node tile of s in LDS, every wave runs
- * v_mfma_f32_16x16x4_f32 (exact fp32) over (hop, 16-node) sub-tiles with the zero-padded hop weights in LDS, and
- * the two activations, the combine and (backward) both weight gradients, both bias gradients, the theta gradient
- * and d(s) come out of the same tile residency: s, h1, h2 cross HBM once per direction.
- *   fwd: writes h1, h2 (saved for backward) and, with theta, out.
- *   bwd: gout is [N,DO] with theta, [N,K,DO] without; writes gs [N,K,DI] and
- *        gflat = [ dW1 (K*DI*DO) | db1 (K*DO) | dW2 (K*DO*DO) | db2 (K*DO) | dtheta (K*DO, only with theta) ],
- *        per-block partials added in block order (deterministic).
- * Limits (KPGNN_ELIMIT beyond): DI, DO <= 32, K * ceil(max(DI,DO)/16)^2 <= 32, K*max(DI,DO) <= 1024.
+ * 6 for K=16), a broadcast multiply + sum and an nn.Linear(dk, hidden) - all far too narrow for a BLAS tile.  Here a
+ * block stages a 32-node tile of s in LDS, every wave runs v_mfma_f32_16x16x4_f32 (exact fp32) over hop slots with
+ * the zero-padded weights in LDS, and the activations, the combine, the projection and (backward) every weight, bias
+ * and theta gradient plus d(s) come out of the same tile residency: s, h1, h2, out cross HBM once per direction.
+ *   fwd: writes h1, h2 (saved for backward) and out ([N,H] with wc, [N,DO] with theta only).
+ *   bwd: gout is [N,H] with wc, [N,DO] with theta only, [N,K,DO] otherwise; writes gs [N,K,DI] and
+ *        gflat = [ dW1 (K*DI*DO) | db1 (K*DO) | dW2 (K*DO*DO) | db2 (K*DO) | dtheta (K*DO, with theta) |
+ *                  dWc (H*DO) | dbc (H) (with wc) ],  per-block partials added in block order (deterministic).
+ * Limits (KPGNN_ELIMIT beyond): DI, DO <= 32; K * ceil(max(DI,DO)/16)^2 <= 32; H <= 1024 and
+ * ceil(H/16) * ceil(max(DI,DO)/16) <= 32; K*max(DI,DO) <= 1024; the LDS footprint (<= 160 KB).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct kpgnn_hop_mlp_desc {
     int64_t N;
     int32_t K, DI, DO;
+    int32_t H;                              /* combine_proj outputs; 0 = no projection */
     const float* s;                         /* device [N,K,DI] contiguous */
     const float* w1; const float* b1;       /* device [K,DI,DO], [K,DO] */
     const float* w2; const float* b2;       /* device [K,DO,DO], [K,DO] */
     const float* theta;                     /* device [K,DO] or NULL */
+    const float* wc; const float* bc;       /* device [H,DO], [H] (bc may be NULL); wc needs theta */
     float* h1; float* h2;                   /* device [N,K,DO] contiguous (fwd: out, bwd: in) */
-    float* out;                             /* device [N,DO] (fwd, with theta) */
+    float* out;                             /* device [N,H] / [N,DO] (fwd, with theta) */
     /* backward only */
-    const float* gout;                      /* device [N,DO] (theta) or [N,K,DO] */
+    const float* gout;                      /* device [N,H] / [N,DO] / [N,K,DO] */
     float* gs;                              /* device [N,K,DI] */
     float* gflat;                           /* device, layout above */
-    void* workspace; size_t workspace_bytes;  /* >= kpgnn_hop_mlp_workspace_bytes(N, K, DI, DO) */
+    void* workspace; size_t workspace_bytes;  /* >= kpgnn_hop_mlp_workspace_bytes(N, K, DI, DO, H) */
 } kpgnn_hop_mlp_desc;
 
-size_t kpgnn_hop_mlp_workspace_bytes(int64_t N, int32_t K, int32_t DI, int32_t DO);
+/* 0 = the shape is not covered (the caller keeps its BLAS path). */
+size_t kpgnn_hop_mlp_workspace_bytes(int64_t N, int32_t K, int32_t DI, int32_t DO, int32_t H);
 int kpgnn_hop_mlp_fwd(const kpgnn_hop_mlp_desc* d, kpgnn_stream_t stream);
 int kpgnn_hop_mlp_bwd(const kpgnn_hop_mlp_desc* d, kpgnn_stream_t stream);
 

@@ -117,9 +117,9 @@ class LinearDesc(ctypes.Structure):
 
 class HopMlpDesc(ctypes.Structure):
     _fields_ = [
-        ("N", c_i64), ("K", c_i32), ("DI", c_i32), ("DO", c_i32),
+        ("N", c_i64), ("K", c_i32), ("DI", c_i32), ("DO", c_i32), ("H", c_i32),
         ("s", c_vp), ("w1", c_vp), ("b1", c_vp), ("w2", c_vp), ("b2", c_vp), ("theta", c_vp),
-        ("h1", c_vp), ("h2", c_vp), ("out", c_vp), ("gout", c_vp), ("gs", c_vp), ("gflat", c_vp),
+        ("wc", c_vp), ("bc", c_vp), ("h1", c_vp), ("h2", c_vp), ("out", c_vp), ("gout", c_vp), ("gs", c_vp), ("gflat", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
     ]
 
@@ -159,7 +159,7 @@ SIGNATURES = {
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
-    "kpgnn_hop_mlp_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i32, c_i32]),
+    "kpgnn_hop_mlp_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "kpgnn_hop_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(HopMlpDesc), c_vp]),
     "kpgnn_hop_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(HopMlpDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),

@@ -189,6 +189,12 @@ table_grad_kernel(const TgParams p) {
             end = min(end, beg + per);
         }
         uint32_t nxt = (beg + lane < end) ? p.tpack[beg + lane] : 0xFFFFFFFFu;   // hop 0xFFF == skip
+        int myuid = -1;                              // lane l: dictionary row of tile row l (NT*K <= 64), in flight during the walk
+        if (p.U > 0 && lane < p.NT * p.K) {
+            const int n = lane / p.K;
+            const int64_t node = tl * p.NT + n;
+            if (node < p.N) myuid = p.uid[node * p.uid_stride + (lane - n * p.K)];
+        }
         if (p.dict_src == 1) {                       // gh rows of the tile's nodes, column t
             for (int n = grp; n < p.NT; n += kGroups) {
                 const int64_t node = tl * p.NT + n;
@@ -240,11 +246,10 @@ table_grad_kernel(const TgParams p) {
             const int64_t node0 = tl * p.NT;
             for (int n = grp; n < p.NT && node0 + n < p.N; n += kGroups) {
                 const float ghv = ghs[n * kCols + t];
-                const int32_t* up = p.uid + (node0 + n) * p.uid_stride;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (k >= p.K) break;
-                    const int u = up[k];                                // wave-uniform
+                    const int u = __builtin_amdgcn_readlane(myuid, n * p.K + k);   // wave-uniform
                     if (u != ucur) {
                         if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
                         ucur = u;

@@ -69,12 +69,16 @@ class KPGINConv(KHopMessagePassing, EdgeCodeTables):
         s = khop_aggregate(x, csr, k_act, MODE_GIN, table0=t0, tablek=tk, periph=peripheral_attr, eps=self.eps,
                            xbias=xbias)                                  # N,K,dk = x_n + P + (1+eps) x
         if self._fused_mlp is None:
-            self._fused_mlp = hop_mlp_supported(self.K, self.input_dk, self.output_dk)
-        if self._fused_mlp:       # per-hop MLP (:106-109) and the geometric combine in one launch per direction
+            geo = isinstance(self.combine, GeometricCombine)
+            self._fused_mlp = 2 if (geo and hop_mlp_supported(self.K, self.input_dk, self.output_dk, self.output_size)) \
+                else (1 if hop_mlp_supported(self.K, self.input_dk, self.output_dk) else 0)
+        mlp = (self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2)
+        if self._fused_mlp == 2:  # per-hop MLP (:106-109), geometric combine and combine_proj (:112): one launch per direction
+            return hop_mlp(s, *mlp, theta=self.combine.theta(), wc=self.combine_proj.weight, bc=self.combine_proj.bias)
+        if self._fused_mlp == 1:
             if isinstance(self.combine, GeometricCombine):
-                return self.combine_proj(hop_mlp(s, self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2,
-                                                 theta=self.combine.theta()))
-            return self.combine_proj(self.combine(hop_mlp(s, self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2)))
+                return self.combine_proj(hop_mlp(s, *mlp, theta=self.combine.theta()))
+            return self.combine_proj(self.combine(hop_mlp(s, *mlp)))
         h = s.transpose(0, 1)                                           # K,N,dk  (hops wider than 32: BLAS)
         h = F.relu(torch.baddbmm(self.hop_bias1.unsqueeze(1), h, self.hop_proj1))
         h = F.relu(torch.baddbmm(self.hop_bias2.unsqueeze(1), h, self.hop_proj2))

@@ -164,63 +164,75 @@ def mlp_linear_bn_relu_x2(mlp, h):
     return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)
 
 
-# ------------------------------------------------------------------------------- KP-GIN per-hop MLP (+ geometric combine)
+# ------------------------------------------------------------------- KP-GIN per-hop MLP (+ geometric combine + projection)
 class HopMlp(torch.autograd.Function):
-    """relu(relu(s W1 + b1) W2 + b2) per hop (+ sum_k theta_k * .), one HIP launch per direction (hop_mlp.hip)."""
+    """relu(relu(s W1 + b1) W2 + b2) per hop (+ sum_k theta_k * . (+ combine_proj)), one HIP launch per direction
+    (hop_mlp.hip)."""
 
     @staticmethod
-    def forward(ctx, s, w1, b1, w2, b2, theta):
+    def forward(ctx, s, w1, b1, w2, b2, theta, wc, bc):
         lib = _lib.load()
         s = s.contiguous()
         N, K, DI = s.shape
         DO = w1.shape[2]
+        H = wc.shape[0] if wc is not None else 0
         dev = s.device
         w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
         theta = theta.contiguous() if theta is not None else None
+        wc = wc.contiguous() if wc is not None else None
+        bc = bc.contiguous() if bc is not None else None
         h = torch.empty((2, N, K, DO), dtype=torch.float32, device=dev)
-        out = torch.empty((N, DO), dtype=torch.float32, device=dev) if theta is not None else None
+        out = torch.empty((N, H if H else DO), dtype=torch.float32, device=dev) if theta is not None else None
         d = _lib.HopMlpDesc()
-        d.N, d.K, d.DI, d.DO = N, K, DI, DO
+        d.N, d.K, d.DI, d.DO, d.H = N, K, DI, DO, H
         d.s, d.w1, d.b1, d.w2, d.b2, d.theta = s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(theta)
+        d.wc, d.bc = _ptr(wc), _ptr(bc)
         d.h1, d.h2, d.out = h[0].data_ptr(), h[1].data_ptr(), _ptr(out)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_hop_mlp_fwd(ctypes.byref(d), _stream(s)), "kpgnn_hop_mlp_fwd")
-        ctx.save_for_backward(s, w1, b1, w2, b2, theta, h)
+        ctx.save_for_backward(s, w1, b1, w2, b2, theta, wc, bc, h)
         return out if theta is not None else h[1]
 
     @staticmethod
     def backward(ctx, gout):
-        s, w1, b1, w2, b2, theta, h = ctx.saved_tensors
+        s, w1, b1, w2, b2, theta, wc, bc, h = ctx.saved_tensors
         lib = _lib.load()
         N, K, DI = s.shape
         DO = w1.shape[2]
+        H = wc.shape[0] if wc is not None else 0
         dev = s.device
         gout = gout.contiguous()
         gs = torch.empty((N, K, DI), dtype=torch.float32, device=dev)
-        sizes = [K * DI * DO, K * DO, K * DO * DO, K * DO] + ([K * DO] if theta is not None else [])
+        sizes = [K * DI * DO, K * DO, K * DO * DO, K * DO] + ([K * DO] if theta is not None else []) + ([H * DO, H] if H else [])
         gflat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        ws_bytes = int(lib.kpgnn_hop_mlp_workspace_bytes(max(N, 1), K, DI, DO))
+        ws_bytes = int(lib.kpgnn_hop_mlp_workspace_bytes(max(N, 1), K, DI, DO, H))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         d = _lib.HopMlpDesc()
-        d.N, d.K, d.DI, d.DO = N, K, DI, DO
+        d.N, d.K, d.DI, d.DO, d.H = N, K, DI, DO, H
         d.s, d.w1, d.b1, d.w2, d.b2, d.theta = s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(theta)
+        d.wc, d.bc = _ptr(wc), _ptr(bc)
         d.h1, d.h2 = h[0].data_ptr(), h[1].data_ptr()
         d.gout, d.gs, d.gflat = gout.data_ptr(), gs.data_ptr(), gflat.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_hop_mlp_bwd(ctypes.byref(d), _stream(s)), "kpgnn_hop_mlp_bwd")
-        parts = torch.split(gflat, sizes)
+        parts = list(torch.split(gflat, sizes))
         gth = parts[4].view(K, DO) if theta is not None else None
-        return gs, parts[0].view(K, DI, DO), parts[1].view(K, DO), parts[2].view(K, DO, DO), parts[3].view(K, DO), gth
+        gwc = parts[-2].view(H, DO) if H else None
+        gbc = parts[-1] if (H and bc is not None) else None
+        return gs, parts[0].view(K, DI, DO), parts[1].view(K, DO), parts[2].view(K, DO, DO), parts[3].view(K, DO), gth, gwc, gbc
 
 
-def hop_mlp_supported(K, DI, DO):
+def hop_mlp_supported(K, DI, DO, H=0):
     """Whether kpgnn_hop_mlp_* covers the shape (wider hops keep the batched-matmul path)."""
-    return int(_lib.load().kpgnn_hop_mlp_workspace_bytes(1, K, DI, DO)) > 0
+    return int(_lib.load().kpgnn_hop_mlp_workspace_bytes(1, K, DI, DO, H)) > 0
 
 
-def hop_mlp(s, w1, b1, w2, b2, theta=None):
-    """s [N,K,DI] -> [N,K,DO] (theta None) or [N,DO] = sum_k theta[k] * h2[:,k] (reference KPGIN.py:106-112)."""
+def hop_mlp(s, w1, b1, w2, b2, theta=None, wc=None, bc=None):
+    """s [N,K,DI] -> h2 [N,K,DO] (theta None), comb [N,DO] = sum_k theta[k] * h2[:,k] (theta), or
+    comb wc^T + bc [N,H] (theta and wc)  (reference KPGIN.py:106-112)."""
     if not s.is_cuda:
         raise _lib.KpgnnError("hop_mlp needs device tensors: there is no CPU path")
-    return HopMlp.apply(s, w1, b1, w2, b2, theta)
+    if wc is not None and theta is None:
+        raise _lib.KpgnnError("hop_mlp: the projection needs theta")
+    return HopMlp.apply(s, w1, b1, w2, b2, theta, wc, bc)

@@ -680,30 +680,44 @@ def test_fused_backward_prepass_equals_two_kernel_path():
 
 @pytest.mark.parametrize("N,K,DI,DO", [(1000, 8, 13, 13), (77, 6, 20, 20), (4099, 16, 6, 6), (130, 3, 5, 9),
                                         (64, 1, 32, 32), (129, 4, 16, 16), (1, 2, 3, 3), (300, 2, 17, 4), (650, 16, 15, 15)])
-@pytest.mark.parametrize("with_theta", [True, False])
-def test_hop_mlp_mfma_vs_torch(N, K, DI, DO, with_theta):
-    """KP-GIN per-hop 2-layer MLP (+ geometric combine) on kpgnn_hop_mlp_*: output and every gradient against the
-    reference's formulation (KPGIN.py:106-112: two batched matmuls + ReLU, combine.py:52-58), fp32 torch on CPU.
-    Asymmetric data catches swapped MFMA operand maps; partial last tiles and padded weight tiles are covered."""
+@pytest.mark.parametrize("head", ["proj", "theta", "plain", "proj_nobias_odd"])
+def test_hop_mlp_mfma_vs_torch(N, K, DI, DO, head):
+    """KP-GIN per-hop 2-layer MLP (+ geometric combine (+ combine_proj)) on kpgnn_hop_mlp_*: output and every gradient
+    against the reference's formulation (KPGIN.py:106-112: two batched matmuls + ReLU, combine.py:52-58, nn.Linear),
+    fp32 torch on CPU.  Asymmetric data catches swapped MFMA operand maps; partial last tiles, padded weight tiles,
+    DI != DO and projection widths that are no multiple of 4 / 16 are covered."""
     from kp_gnn_amd.ops_dense import hop_mlp
     dev = _dev()
     g = torch.Generator().manual_seed(N * 31 + K)
+    with_theta = head != "plain"
+    H = {"proj": K * DO, "proj_nobias_odd": K * DO + 3}.get(head, 0)
     s = torch.randn(N, K, DI, generator=g) * (1 + 0.05 * torch.arange(DI))
     w1 = torch.randn(K, DI, DO, generator=g) * 0.4
     b1 = torch.randn(K, DO, generator=g) * 0.3
     w2 = torch.randn(K, DO, DO, generator=g) * 0.4
     b2 = torch.randn(K, DO, generator=g) * 0.3
-    th = torch.softmax(torch.randn(K, DO, generator=g), dim=0) if with_theta else None
-    gy = torch.randn(*((N, DO) if with_theta else (N, K, DO)), generator=g) * (1 + 0.02 * torch.arange(DO))
-    leaves = [t.clone().requires_grad_(True) for t in (s, w1, b1, w2, b2)] + ([th.clone().requires_grad_(True)] if with_theta else [])
+    cpu = [s, w1, b1, w2, b2]
+    names = ["ds", "dW1", "db1", "dW2", "db2"]
+    if with_theta:
+        cpu.append(torch.softmax(torch.randn(K, DO, generator=g), dim=0)); names.append("dtheta")
+    if H:
+        cpu.append(torch.randn(H, DO, generator=g) * 0.5); names.append("dWc")
+        if head == "proj":
+            cpu.append(torch.randn(H, generator=g)); names.append("dbc")
+    oshape = (N, H) if H else ((N, DO) if with_theta else (N, K, DO))
+    gy = torch.randn(*oshape, generator=g) * (1 + 0.02 * torch.arange(oshape[-1]))
+    leaves = [t.clone().requires_grad_(True) for t in cpu]
     h = leaves[0].transpose(0, 1)
     h = torch.relu(torch.matmul(h, leaves[1]) + leaves[2].unsqueeze(1))
-    h = torch.relu(torch.matmul(h, leaves[3]) + leaves[4].unsqueeze(1)).transpose(0, 1)
-    ref = (h * leaves[5].unsqueeze(0)).sum(dim=-2) if with_theta else h
+    ref = torch.relu(torch.matmul(h, leaves[3]) + leaves[4].unsqueeze(1)).transpose(0, 1)
+    if with_theta:
+        ref = (ref * leaves[5].unsqueeze(0)).sum(dim=-2)
+    if H:
+        ref = torch.nn.functional.linear(ref, leaves[6], leaves[7] if head == "proj" else None)
     (ref * gy).sum().backward()
-    dl = [t.clone().to(dev).requires_grad_(True) for t in (s, w1, b1, w2, b2)] + ([th.clone().to(dev).requires_grad_(True)] if with_theta else [])
-    out = hop_mlp(*dl[:5], theta=dl[5] if with_theta else None)
+    dl = [t.clone().to(dev).requires_grad_(True) for t in cpu]
+    out = hop_mlp(*dl[:5], theta=dl[5] if with_theta else None, wc=dl[6] if H else None, bc=dl[7] if head == "proj" else None)
     (out * gy.to(dev)).sum().backward()
     _close(out, ref, "out", rtol=2e-4, atol=2e-5)
-    for name, a, b in zip(("ds", "dW1", "db1", "dW2", "db2", "dtheta"), dl, leaves):
+    for name, a, b in zip(names, dl, leaves):
         _close(a.grad, b.grad, name, rtol=2e-4, atol=2e-5)
