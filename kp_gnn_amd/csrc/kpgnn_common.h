@@ -58,6 +58,11 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr);
 
+// Count-matrix x g-tile table gradients on the matrix cores (table_grad_mfma.hip): *handled tells whether the launch
+// was done; otherwise kpgnn_table_grad falls back to its register-walk kernel.
+int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled);
+size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int U);
+
 // erf(z) by Abramowitz-Stegun 7.1.26 (max abs error 5.4e-7 in fp32 over [-6,6]; exact +-1 beyond): ~14 VALU ops
 // against ~30 for libm's erff, which made the GELU epilogue VALU-bound (28 us of a 160 us launch).  Also
 // returns e2 = exp(-z*z), which the backward needs for the Gaussian density.

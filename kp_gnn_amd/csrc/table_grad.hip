@@ -356,9 +356,10 @@ extern "C" size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t
                                                    int32_t n_code0, int32_t n_codek, int32_t n_dict) {
     Plan pl;
     if (N <= 0 || K < 1 || D < 1 || nodes_per_tile < 1) return 0;
+    const size_t mfma = table_grad_mfma_ws_bytes(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict);
     // (sized for the fused pre-pass as well: K extra theta-gradient rows)
-    if (make_plan(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict, &pl, K) != KPGNN_OK) return 0;
-    return pl.ws_bytes;  // 0 also means "does not fit": the caller then takes its atomic fallback
+    if (make_plan(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict, &pl, K) != KPGNN_OK) return mfma;
+    return pl.ws_bytes > mfma ? pl.ws_bytes : mfma;  // 0 means "neither kernel fits": the caller takes its atomic fallback
 }
 
 extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream) {
@@ -380,11 +381,25 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
                   (d->dict_src == 2 || (d->dict_src == 1 && d->theta && d->gh)))),
                   "table_grad: dictionary gradient needs uid/gdict and (theta, gh) or dict_src 2");
     KPGNN_REQUIRE(edges || d->n_dict > 0 || fuse, "table_grad: nothing to do");
+    hipStream_t s = (hipStream_t)stream;
+    KPGNN_REQUIRE(fuse || (d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D), "table_grad: g must be contiguous [N,K,D]");
+    {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
+        // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
+        // dictionary rows) at D = 13.  Wide rows stay on the register walk (D = 104: 78 vs 121 us; the 16x16x4 product
+        // is matrix-core bound there).  KPGNN_TG_KERNEL=walk|mfma forces one of them.
+        static const int force = [] { const char* e = getenv("KPGNN_TG_KERNEL");
+                                      return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+        const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows;
+        if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
+            bool handled = false;
+            const int rc = table_grad_mfma(d, s, &handled);
+            if (rc != KPGNN_OK || handled) return rc;
+        }
+    }
     TgParams p;
     p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
     p.n0 = edges ? d->n_code0 : 0; p.nk = (edges && d->K > 1) ? d->n_codek : 0;
     p.U = d->n_dict; p.dict_src = d->dict_src;
-    KPGNN_REQUIRE(fuse || (d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D), "table_grad: g must be contiguous [N,K,D]");
     p.pre = d->fuse_pre; p.ptab = d->fuse_ptab; p.gout = d->fuse_g; p.mode = d->fuse_mode; p.want_gth = (fuse && d->gtheta) ? 1 : 0;
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
@@ -395,7 +410,6 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     p.slab = (float*)d->workspace;
-    hipStream_t s = (hipStream_t)stream;
     // the tile copy is flat: 16-B loads only need every node's K*D floats to be a multiple of 4
     const bool vec4 = (((int64_t)p.K * p.D) % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
     if (fuse) {

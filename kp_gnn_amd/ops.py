@@ -1,5 +1,6 @@
 """Autograd operators over the C ABI (include/kpgnn.h).  Host-side plumbing only: tensors in, pointers
 and strides out; every arithmetic step of the K-hop aggregation runs in the HIP kernels."""
+import contextlib
 import ctypes
 import os as _os
 
@@ -42,6 +43,21 @@ _timer = None
 # Fused backward pre-pass (g, theta grad, table grads, dictionary grads in ONE launch of table_grad_kernel) is opt-in:
 # the 512-thread tile kernel does the erf arithmetic at lower occupancy than the streaming combine_bwd kernel and the
 # step came out 2 % slower (8.89 vs 8.69 ms at B = 2048).  KPGNN_FUSED_BWD=1 enables it; both paths are parity-tested.
+# measured (B=2048, hipGraph replay): forking table_grad onto a side stream is SLOWER (KP-GIN+ 8.92 vs 8.37 ms,
+# KP-GIN 5.33 vs 4.90 ms per step): the two kernels contend for the same CUs and the fork/join adds graph edges.
+_overlap_bwd = _os.environ.get("KPGNN_OVERLAP_BWD", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One extra HIP stream per device for the backward's independent kernels (fork/join by events: capturable)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 _fused_bwd = _os.environ.get("KPGNN_FUSED_BWD", "0") == "1"
 # The LDS-staged forward kernel (aggregate_lds.hip) is opt-in: at K*D ~ 832 floats per node a tile's rows only fit
 # LDS hop by hop, the per-hop barriers then cost more than the dependent global loads they remove (measured
@@ -413,14 +429,22 @@ class KHopAggregate(torch.autograd.Function):
         # --- table gradients (edge codes + peripheral dictionary), column-private kernel
         gt0 = gtk = None
         tables_in_gather = False
+        side = main = None
         if want_tables or want_gdict:
             edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
             dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
             res = None
             if edges_here or dict_here:
-                res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
-                                     uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
-                                     theta=theta if fused else None, gh=gout if fused else None)
+                # table_grad (latency / SALU bound walk) and aggregate_bwd (gather, issue bound) both only READ g:
+                # fork the former onto a side stream so the two overlap; joined below before anything is returned
+                if _overlap_bwd:
+                    main = torch.cuda.current_stream(g.device)
+                    side = _side_stream(g.device)
+                    side.wait_stream(main)
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
+                                         uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
+                                         theta=theta if fused else None, gh=gout if fused else None)
             if res is not None:
                 gt0, gtk, gdict = res
             if want_tables and (res is None or not edges_here):
@@ -434,6 +458,8 @@ class KHopAggregate(torch.autograd.Function):
                 gdict = r2[2]
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
                                        slots=ctx.n_slots > 0)
+        if side is not None:
+            main.wait_stream(side)
         if tables_in_gather:
             gt0, gtk = a0, ak
         geps = None
