@@ -298,6 +298,7 @@ typedef struct kpgnn_bn_desc {
     float* z;  int64_t z_stride;            /* device [N,C] output */
     const float* residual; int64_t r_stride;/* optional: z += residual (after the activation) */
     void* workspace; size_t workspace_bytes;/* >= kpgnn_bn_workspace_bytes(C) */
+    int64_t* num_batches_tracked;           /* device scalar, += 1 per call, or NULL (nn.BatchNorm1d's counter) */
 } kpgnn_bn_desc;
 
 typedef struct kpgnn_bn_bwd_desc {
@@ -384,6 +385,14 @@ typedef struct kpgnn_attn_desc {
 
 int kpgnn_attn_fwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
 int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
+
+/* Geometric hop-combine weights (reference layers/combine.py:43-50, GeometricCombine.geometric_distribution):
+ *     a = sigmoid(alpha[d]);  theta[k,d] = softmax_k( a (1-a)^k )            theta: device [K,D], alpha: device [D]
+ * and the backward  galpha[d] = d/dalpha sum_k gtheta[k,d] theta[k,d].  One launch each (the op-by-op version is
+ * 6 + 20 launches per layer on a ~100-element tensor). */
+int kpgnn_geo_theta_fwd(const float* alpha, int32_t K, int32_t D, float* theta, kpgnn_stream_t stream);
+int kpgnn_geo_theta_bwd(const float* alpha, const float* theta, const float* gtheta, int32_t K, int32_t D,
+                        float* galpha, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KP-GIN per-hop MLP + geometric hop-combine + combine_proj (reference layers/KPGIN.py:106-112, combine.py:52-58):

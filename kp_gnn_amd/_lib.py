@@ -77,7 +77,7 @@ class BnDesc(ctypes.Structure):
         ("x", c_vp), ("x_stride", c_i64), ("gamma", c_vp), ("beta", c_vp),
         ("running_mean", c_vp), ("running_var", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("z", c_vp), ("z_stride", c_i64), ("residual", c_vp), ("r_stride", c_i64),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("num_batches_tracked", c_vp),
     ]
 
 
@@ -159,6 +159,8 @@ SIGNATURES = {
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
+    "kpgnn_geo_theta_fwd": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "kpgnn_geo_theta_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_hop_mlp_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "kpgnn_hop_mlp_fwd": (ctypes.c_int, [ctypes.POINTER(HopMlpDesc), c_vp]),
     "kpgnn_hop_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(HopMlpDesc), c_vp]),

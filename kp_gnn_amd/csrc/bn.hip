@@ -36,11 +36,14 @@ struct BnParams {
     float* z; int64_t zs;              // fwd output / bwd dx
     const float* res; int64_t rs;
     float* slab;                       // [gridDim.x][2][C]
-    const float* sums;                 // [2][C] reduced
+    float* sums;                       // [2][C] reduced
+    int64_t* nbt;                      // num_batches_tracked or NULL
     float* dgamma; float* dbeta;
 };
 
 // Block reduction of per-thread (a,b)[VEC] over the row-lanes, then one slab row per block.
+// (Letting the last block to finish add the slab up in-kernel was tried: one block pulling 512 x 2C partials through
+//  L2 takes far longer than the ~4.6 us launch of the 2C/16-block ordered slab_reduce it would save.)
 template <int VEC, int G>
 __device__ __forceinline__ void block_to_slab(const BnParams& p, float (&a)[VEC], float (&b)[VEC], int c0, bool col_ok) {
     __shared__ float red[2][kBlock / G][G * VEC];
@@ -55,6 +58,7 @@ __device__ __forceinline__ void block_to_slab(const BnParams& p, float (&a)[VEC]
             p.slab[((int64_t)blockIdx.x * 2 + 1) * p.C + c0 + q] = s1;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;   // nn.BatchNorm1d.num_batches_tracked
 }
 
 // fwd stats: s0 = sum (x - pivot), s1 = sum (x - pivot)^2, pivot = x[0, c]
@@ -232,6 +236,7 @@ extern "C" int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream) {
     p.slab = (float*)d->workspace;
     float* sums = p.slab + (size_t)kStatBlocks * 2 * d->C;
     p.sums = sums;
+    p.nbt = d->num_batches_tracked;
     hipStream_t s = (hipStream_t)stream;
     int nstat = stream_grid(d->N, g);
     if (nstat > kStatBlocks) nstat = kStatBlocks;
@@ -260,6 +265,7 @@ extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
     p.slab = (float*)d->workspace;
     float* sums = p.slab + (size_t)kStatBlocks * 2 * d->C;
     p.sums = sums;
+    p.nbt = nullptr;
     hipStream_t s = (hipStream_t)stream;
     int nstat = stream_grid(d->N, g);
     if (nstat > kStatBlocks) nstat = kStatBlocks;

@@ -43,10 +43,15 @@ class GeometricCombine(nn.Module):
         return torch.softmax(thetas, dim=0).unsqueeze(0)                              # 1,K,D
 
     def theta(self):
-        """[K, D] contiguous weights for the fused kernel epilogue."""
+        """[K, D] contiguous weights for the fused kernel epilogues (one HIP launch; fp32 device parameters)."""
+        if self.alphas.is_cuda and self.alphas.dtype == torch.float32:
+            from ..ops_dense import geo_theta
+            return geo_theta(self.alphas, self.K)
         return self.geometric_distribution().squeeze(0).contiguous()
 
     def forward(self, x):
+        if self.alphas.is_cuda and self.alphas.dtype == torch.float32:
+            return torch.sum(x * self.theta().unsqueeze(0), dim=-2)
         return torch.sum(x * self.geometric_distribution(), dim=-2)
 
 

@@ -11,17 +11,30 @@ from . import _lib
 from .ops import _ptr, _stream
 
 
+_bn_ws = {}
+
+
+def _bn_workspace(lib, dev, C):
+    """Persistent per-(device, C) scratch for the partial sums (no allocator round trip per call).  BatchNorm launches
+    of one device are stream-ordered (one compute stream, or one captured graph), so they can share it."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), C)
+    ent = _bn_ws.get(key)
+    if ent is None:
+        nb = int(lib.kpgnn_bn_workspace_bytes(C))
+        ent = _bn_ws[key] = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
+    return ent
+
+
 class BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None):
         lib = _lib.load()
         x = x if x.stride(-1) == 1 else x.contiguous()
         N, C = x.shape
         dev = x.device
         z = torch.empty((N, C), dtype=torch.float32, device=dev)
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
-        ws_bytes = lib.kpgnn_bn_workspace_bytes(C)
-        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        ws, ws_bytes = _bn_workspace(lib, dev, C)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
         d.x, d.x_stride = x.data_ptr(), x.stride(0)
@@ -33,6 +46,7 @@ class BatchNormAct(torch.autograd.Function):
             residual = residual if residual.stride(-1) == 1 else residual.contiguous()
             d.residual, d.r_stride = residual.data_ptr(), residual.stride(0)
         d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+        d.num_batches_tracked = _ptr(nbt)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
@@ -49,8 +63,7 @@ class BatchNormAct(torch.autograd.Function):
         dev = x.device
         dx = torch.empty((N, C), dtype=torch.float32, device=dev)
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
-        ws_bytes = lib.kpgnn_bn_workspace_bytes(C)
-        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        ws, ws_bytes = _bn_workspace(lib, dev, C)
         d = _lib.BnBwdDesc()
         d.N, d.C, d.relu = N, C, 1 if ctx.relu else 0
         d.x, d.x_stride, d.dz, d.dz_stride = x.data_ptr(), x.stride(0), dz.data_ptr(), dz.stride(0)
@@ -60,7 +73,7 @@ class BatchNormAct(torch.autograd.Function):
         d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_bwd")
-        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None
+        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None, None
 
 
 import os as _os
@@ -145,10 +158,9 @@ def batch_norm_act(x, bn, relu=False, residual=None):
     use_hip = (bn.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and bn.affine
                and bn.momentum is not None and x.shape[1] <= 256 and x.shape[0] >= 1)
     if use_hip:
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu)
+        nbt = bn.num_batches_tracked if bn.track_running_stats else None   # incremented inside the stats kernel
+        return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt)
     out = bn(x)
     if relu:
         out = F.relu(out)
@@ -236,3 +248,36 @@ def hop_mlp(s, w1, b1, w2, b2, theta=None, wc=None, bc=None):
     if wc is not None and theta is None:
         raise _lib.KpgnnError("hop_mlp: the projection needs theta")
     return HopMlp.apply(s, w1, b1, w2, b2, theta, wc, bc)
+
+
+# ------------------------------------------------------------------------------------ geometric hop-combine weights
+class GeoTheta(torch.autograd.Function):
+    """theta[k,d] = softmax_k(a (1-a)^k), a = sigmoid(alphas[d])  (combine.py:43-50): one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, alphas, K):
+        lib = _lib.load()
+        alphas = alphas.contiguous()
+        D = alphas.numel()
+        theta = torch.empty((K, D), dtype=torch.float32, device=alphas.device)
+        with torch.cuda.device(alphas.device):
+            _lib.check(lib.kpgnn_geo_theta_fwd(alphas.data_ptr(), K, D, theta.data_ptr(), _stream(alphas)), "kpgnn_geo_theta_fwd")
+        ctx.save_for_backward(alphas, theta)
+        ctx.K = K
+        return theta
+
+    @staticmethod
+    def backward(ctx, gtheta):
+        alphas, theta = ctx.saved_tensors
+        lib = _lib.load()
+        gtheta = gtheta.contiguous()
+        D = alphas.numel()
+        ga = torch.empty_like(alphas)
+        with torch.cuda.device(alphas.device):
+            _lib.check(lib.kpgnn_geo_theta_bwd(alphas.data_ptr(), theta.data_ptr(), gtheta.data_ptr(), ctx.K, D, ga.data_ptr(),
+                                               _stream(alphas)), "kpgnn_geo_theta_bwd")
+        return ga, None
+
+
+def geo_theta(alphas, K):
+    return GeoTheta.apply(alphas, K)
