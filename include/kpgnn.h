@@ -175,6 +175,9 @@ typedef struct kpgnn_agg_bwd_desc {
     /* Per-hop outputs (used when gx == NULL): the gradient of hop slot k goes to gx_slot[k], [N,D] with row
      * stride gx_sn (the backward of the per-hop inputs above: no [N,k,D] tensor to slice up afterwards). */
     float* gx_slot[16];
+    /* Bit k set: ADD the gradient of hop slot k to what gx_slot[k] already holds (a state that several layers read as
+     * a slot collects its gradient in one buffer instead of one tensor per reader plus an add each). */
+    uint32_t accumulate_mask;
 } kpgnn_agg_bwd_desc;
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);

@@ -42,7 +42,7 @@ class AggBwdDesc(ctypes.Structure):
         ("eps", c_vp),
         ("gx", c_vp), ("gx_sn", c_i64), ("gx_sk", c_i64),
         ("gtable0", c_vp), ("gtablek", c_vp),
-        ("gx_slot", c_vp * 16),
+        ("gx_slot", c_vp * 16), ("accumulate_mask", ctypes.c_uint32),
     ]
 
 

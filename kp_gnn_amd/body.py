@@ -359,7 +359,8 @@ class GNNPlus(_KHopBody):
             slots = [h_list[l - m] for m in range(k)]                  # slot m = state of layer l-m
             pek = pe_attr[:, :k - 1] if pe_attr is not None else None
             if hasattr(self.gnns[l], "forward_slots") and slots[0].is_cuda:
-                h = self.gnns[l].forward_slots(slots, edge_index, edge_attr[:, :k], pek, periph[:, :k])
+                # (history=True: slot m is the state of layer l-m, so the layers may pool their slot gradients per state)
+                h = self.gnns[l].forward_slots(slots, edge_index, edge_attr[:, :k], pek, periph[:, :k], history=True)
             else:
                 h = self.gnns[l](torch.stack(slots, dim=1), edge_index, edge_attr[:, :k], pek, periph[:, :k])
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)

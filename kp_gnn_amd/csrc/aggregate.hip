@@ -203,6 +203,7 @@ struct BwdParams {
     float* gtable0;
     float* gtablek;
     float* gxs[16];             // per-hop outputs (gx == NULL)
+    uint32_t acc_mask;          // bit k: gxs[k] += instead of =
 };
 
 // TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
@@ -291,7 +292,9 @@ agg_bwd_kernel(const BwdParams p) {
                     for (int q = 0; q < VEC; ++q) atomicAdd(dst + q, self.v[q]);
                 }
             }
-            acc.store((p.gx ? p.gx + (int64_t)k * p.gx_sk : p.gxs[k]) + j * p.gx_sn + c0);
+            float* dst = (p.gx ? p.gx + (int64_t)k * p.gx_sk : p.gxs[k]) + j * p.gx_sn + c0;
+            if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(V<VEC>::load(dst));   // one sub-group owns the row: no atomics
+            acc.store(dst);
         }
     }
     if (TAB == 1) {
@@ -487,6 +490,7 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         p.gxs[k] = (!d->gx && k < d->K) ? d->gx_slot[k] : nullptr;
         if (p.gxs[k] && (!slot_align || ((uintptr_t)p.gxs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.gxs[k];
     }
+    p.acc_mask = d->gx ? 0u : d->accumulate_mask;
     const int vec = pick_vec(d->D, {d->g, d->gx ? (const void*)d->gx : slot_align}, {d->g_sn, d->g_sk, d->gx_sn, d->gx ? d->gx_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_bwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);

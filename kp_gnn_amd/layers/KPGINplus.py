@@ -36,25 +36,25 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
         if self.K > 1:
             self.combine.reset_parameters()
 
-    def forward_slots(self, h_slots, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
+    def forward_slots(self, h_slots, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, history=False):
         """Same as forward(torch.stack(h_slots, 1), ...) without the stacking copy (and without the slicing
         adds in backward): hop slot m reads h_slots[m] ([N,H]) where it lives.  Extension of the reference API
         used by kp_gnn_amd.body.GNNPlus; GNNs.py:413-418 builds the stack with torch.cat every layer."""
         from ..khop_csr import path_encoding_is_zero
         if self.K > 1 and pe_attr is not None and not path_encoding_is_zero(pe_attr):
             return self.forward(torch.stack(list(h_slots), dim=1), edge_index, edge_attr, pe_attr, peripheral_attr)
-        return self.forward(list(h_slots), edge_index, edge_attr, pe_attr, peripheral_attr)
+        return self.forward(list(h_slots), edge_index, edge_attr, pe_attr, peripheral_attr, _history=history)
 
-    def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
+    def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, _history=False):
         n = x[0].size(0) if isinstance(x, list) else x.size(0)
         csr, k_act = self._csr(edge_index, edge_attr, n)
         x, xbias = self._path_encoding(x, pe_attr)
         t0, tk = self._tables()
         if isinstance(self.combine, GeometricCombine):
             h = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
-                               theta=self.combine.theta(), xbias=xbias)                      # N,H
+                               theta=self.combine.theta(), xbias=xbias, share_slot_grads=_history)   # N,H
         else:
             xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
-                                xbias=xbias)                                                  # N,k,H
+                                xbias=xbias, share_slot_grads=_history)                       # N,k,H
             h = self.combine(xn)
         return mlp_linear_bn_relu_x2(self.mlp, h)

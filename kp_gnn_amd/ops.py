@@ -196,9 +196,10 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     return out, pre
 
 
-def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False):
+def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False, slot_bufs=None):
     """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek); with slots=True gx is a list of
-    k contiguous [N,D] tensors (one per hop slot) instead of one [N,k,D] tensor."""
+    k contiguous [N,D] tensors (one per hop slot) instead of one [N,k,D] tensor; slot_bufs[k] (a [N,D] tensor or None)
+    makes the kernel ADD slot k's gradient into that buffer instead of writing a fresh one."""
     lib = _lib.load()
     N, K, D = g.shape
     dev = g.device
@@ -213,8 +214,13 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     if slots:
         gx = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(K)]
         d.gx_sn = D
-        for k, t in enumerate(gx):
-            d.gx_slot[k] = t.data_ptr()
+        mask = 0
+        for k in range(K):
+            if slot_bufs is not None and slot_bufs[k] is not None:
+                gx[k] = slot_bufs[k]
+                mask |= 1 << k
+            d.gx_slot[k] = gx[k].data_ptr()
+        d.accumulate_mask = mask
     else:
         gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
         d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
@@ -356,7 +362,8 @@ class KHopAggregate(torch.autograd.Function):
     kpgnn_aggregate_bwd (the transposed gather for dL/dx)."""
 
     @staticmethod
-    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, *xs):
+    def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, cells, *xs):
+        ctx.cells = cells
         _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
         ctx.n_slots = len(xs)
         if xs:   # per-hop inputs: k separate [N,D] states instead of one stacked [N,k,D] tensor
@@ -413,11 +420,12 @@ class KHopAggregate(torch.autograd.Function):
             if res is not None:
                 gt0, gtk, gdict, g, gtheta = res
                 gx, _, _ = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, False,
-                                             slots=ctx.n_slots > 0)
+                                             slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
                 if ctx.n_slots:
-                    return (None, gt0, gtk, None, None, gtheta, None, gdict, None, None, None, None, *gx)
+                    return (None, gt0, gtk, None, None, gtheta, None, gdict, None, None, None, None, None,
+                            *_slot_grads(ctx, gx))
                 return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, None, None, gtheta, None, gdict,
-                        None, None, None, None)
+                        None, None, None, None, None)
         if fused or need_act:
             g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
                                             want_gtheta=fused and ctx.needs_input_grad[5],
@@ -457,7 +465,7 @@ class KHopAggregate(torch.autograd.Function):
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
-                                       slots=ctx.n_slots > 0)
+                                       slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
         if side is not None:
             main.wait_stream(side)
         if tables_in_gather:
@@ -471,20 +479,63 @@ class KHopAggregate(torch.autograd.Function):
         # (row 0 of both table grads stays exactly zero: code 0 == "inactive" never enters the CSR, which
         #  is also what nn.Embedding(padding_idx=0) would do)
         if ctx.n_slots:
-            return (None, gt0, gtk, gperiph, geps, gtheta, None, gdict, None, None, None, None, *gx)
+            return (None, gt0, gtk, gperiph, geps, gtheta, None, gdict, None, None, None, None, None,
+                    *_slot_grads(ctx, gx))
         return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta, None, gdict,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None):
+class _SlotGradCell:
+    """Gradient buffer of one state tensor that several layers read as a hop slot (see khop_aggregate)."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+def _slot_bufs(ctx):
+    return [c.buf for c in ctx.cells] if ctx.cells else None
+
+
+def _slot_grads(ctx, gx):
+    """With shared cells: slots >= 1 park their gradient in the state's cell (the kernel has added to it) and hand
+    autograd nothing; slot 0 - by construction the LAST of a state's readers to run backward - returns the total."""
+    if not ctx.cells:
+        return gx
+    out = []
+    for k, c in enumerate(ctx.cells):
+        if k == 0:
+            out.append(gx[0])
+            c.buf = None
+        else:
+            c.buf = gx[k]
+            out.append(None)
+    return out
+
+
+def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None,
+                   share_slot_grads=False):
     """x: [N,k,D] tensor, or a list/tuple of k per-hop [N,D] tensors (no stacking copy).
-    periph: dense [N,k,D] tensor, a DictPeripheral, or None."""
+    periph: dense [N,k,D] tensor, a DictPeripheral, or None.
+    share_slot_grads (per-hop list only): the caller guarantees the GNNPlus history pattern - slot k of layer m is the
+    output of layer m-1-k, so every state is read as slot 0 by the layer right after it and as slots >= 1 only by LATER
+    layers, whose backward autograd runs first.  The backward then accumulates a state's slot gradients in ONE buffer
+    inside the gather kernel (kpgnn_agg_bwd_desc.accumulate_mask) instead of emitting one [N,D] tensor per reader
+    for autograd to add up (36 adds of 19.7 MB per step at K = L = 8)."""
     ptab = uid = None
     if isinstance(periph, DictPeripheral):
         ptab, uid, periph = periph.table, periph.uid, None
     if isinstance(x, (list, tuple)):
-        return KHopAggregate.apply(None, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, *x)
-    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid)
+        cells = None
+        if share_slot_grads and torch.is_grad_enabled():
+            cells = []
+            for t in x:
+                c = getattr(t, "_kp_slot_cell", None)
+                if c is None:
+                    c = t._kp_slot_cell = _SlotGradCell()
+                cells.append(c)
+        return KHopAggregate.apply(None, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, cells, *x)
+    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, None)
 
 
 class DictRows(torch.autograd.Function):

@@ -127,7 +127,8 @@ class LinearWgrad(torch.autograd.Function):
         dev = dy.device
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _mfma_linear(dy, weight.t().contiguous(), None)   # dx = dy W  ==  dy (W^T)^T
+            # dx = dy W  ==  dy (W^T)^T  (the transposed copy is only made when the opt-in MFMA forward kernel is on)
+            dx = _mfma_linear(dy, weight.t().contiguous(), None) if _USE_MFMA_LINEAR else None
             if dx is None:
                 dx = dy @ weight
         dw = torch.empty((O, I), dtype=torch.float32, device=dev)
