@@ -103,6 +103,8 @@ agg_fwd_kernel(const FwdParams p) {
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
     const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+    const uint32_t xrow_b = (uint32_t)p.x_sn * 4u, trow_b = (uint32_t)D * 4u;   // (host: N * x_sn * 4 < 2^32)
+    const uint32_t lane_b = col_ok ? (uint32_t)c0 * 4u : 0u;   // idle lanes re-read column 0 and are dropped below
 
     int last_u = -1;                        // dictionary row held in registers
     V<VEC> prow = V<VEC>::zero();
@@ -113,44 +115,160 @@ agg_fwd_kernel(const FwdParams p) {
         if (i >= p.N) continue;             // whole sub-group leaves together
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
-        int beg = rp[0];
+        // The waves of this kernel sit in s_waitcnt 85 % of their cycles (PMC, profiles/r01): per hop there were three
+        // DEPENDENT round trips (row pointer -> pair list -> neighbour rows, then uid -> dictionary row).  So the node's
+        // K+1 row pointers, its K dictionary ids and its whole pair list (all hops, one chunk of G pairs at a time -
+        // a ZINC node has ~21) are fetched up front by the lanes of the sub-group and handed out with ds_bpermute.
+        const bool lane_meta = G > p.K;                    // K+1 row pointers fit the sub-group's lanes
+        int myrp = 0, myuid = 0;
+        if (lane_meta) {
+            myrp = rp[sl <= p.K ? sl : p.K];
+            if (p.uid && !p.periph) myuid = p.uid[i * p.uid_stride + (sl < p.K ? sl : 0)];
+        }
+        int beg = lane_meta ? __shfl(myrp, sg_lane0) : rp[0];
+        const int end_all = lane_meta ? __shfl(myrp, sg_lane0 + p.K) : rp[p.K];
+        // pair-list chunk [cbase, cbase+G): lane sl holds the byte offsets of pair cbase+sl (non-GCN path)
+        int cbase = beg;
+        uint32_t coff = 0, ctab = 0;
+        if (!GCN) {
+            const int idx = cbase + sl;
+            if (idx < end_all) {
+                coff = (uint32_t)p.col[idx] * xrow_b;
+                if (TAB != 0) ctab = (uint32_t)p.code[idx] * trow_b;
+            }
+        }
+        // Rows of the NEXT hop's first pairs are requested before the current hop is summed and finished, so the one
+        // dependent round trip left per hop (the neighbour rows) overlaps the previous hop's epilogue.
+        constexpr int PF = G >= 32 ? 4 : 2;   // (narrow rows, 4+ nodes per wave: deeper prefetch measured slower, 60 vs 49 us at D = 13)
+        V<VEC> pr[PF];
+        uint32_t prb[PF];
+        int prn = 0;
+        auto prefetch = [&](int kk, int bpos, int bend) {
+            prn = min(PF, min(bend, cbase + G) - bpos);
+            if (prn < 0) prn = 0;
+            const char* xb = reinterpret_cast<const char*>(p.x ? p.x + (int64_t)kk * p.x_sk : p.xs[kk]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (u < prn) {
+                    const int l = sg_lane0 + (bpos - cbase) + u;
+                    const uint32_t o = __shfl(coff, l);
+                    if (TAB != 0) prb[u] = __shfl(ctab, l);
+                    pr[u] = V<VEC>::load(reinterpret_cast<const float*>(xb + (size_t)(o + lane_b)));
+                }
+            }
+        };
+        int end_next = lane_meta ? __shfl(myrp, sg_lane0 + 1) : rp[1];
+        if (!GCN) prefetch(0, beg, end_next);
         for (int k = 0; k < p.K; ++k) {
-            const int end = rp[k + 1];
+            const int end = end_next;
+            if (GCN && k + 1 < p.K) end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
+            const int uk = lane_meta ? __shfl(myuid, sg_lane0 + k) : 0;     // (shuffles need the whole sub-group active)
             const float* xk = (p.x ? p.x + (int64_t)k * p.x_sk : p.xs[k]) + c0;
             const float* tab = k == 0 ? tab0 : tabk;
             V<VEC> acc = V<VEC>::zero();
             float wacc = 0.f;  // GCN: sum of edge weights of the segment (for the constant x-bias term)
-            for (int base = beg; base < end; base += G) {
-                const int idx = base + sl;
-                int myj = 0, myc = 0;
-                if (idx < end) {
-                    myj = p.col[idx];
-                    if (TAB != 0) myc = p.code[idx];
+            // Each lane of the sub-group fetches ONE pair of the segment and turns it into byte offsets (row of x,
+            // row of the code table) once; the gather loop then only broadcasts two 32-bit offsets per pair
+            // (ds_bpermute) and adds the lane's column offset: no 64-bit / quarter-rate integer math per pair
+            // (it was ~20 of the ~35 VALU slots a pair cost).  Two pairs per trip + a one-pair tail: segments hold
+            // 2.7 pairs on average, a 4-deep body mostly ran masked.
+            const char* xkb = reinterpret_cast<const char*>(p.x ? p.x + (int64_t)k * p.x_sk : p.xs[k]);   // wave-uniform
+            const char* tabb = reinterpret_cast<const char*>(tab);
+            if (!GCN) {
+                V<VEC> cur[PF];
+                uint32_t curb[PF];
+                const int cn = prn;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) { cur[u] = pr[u]; curb[u] = prb[u]; }
+                if (k + 1 < p.K) {
+                    end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
+                    prefetch(k + 1, end, end_next);
                 }
-                float myw = 1.0f;
-                if (GCN && idx < end) myw = p.dis[(int64_t)myj * p.K_csr + k];
-                const int cnt = min(G, end - base);
-                for (int t = 0; t < cnt; t += 4) {
-                    int j[4], c[4]; float wgt[4]; V<VEC> r[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
-                        j[u] = __shfl(myj, srcl);
-                        if (TAB != 0) c[u] = __shfl(myc, srcl);
-                        if (GCN) wgt[u] = __shfl(myw, srcl);
+                for (int u = 0; u < PF; ++u) {
+                    if (u < cn) {
+                        if (TAB != 0) cur[u].add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(curb[u] + lane_b))));
+                        acc.add(cur[u]);
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        r[u] = V<VEC>::zero();
-                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(xk + (int64_t)j[u] * p.x_sn);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (t + u < cnt && col_ok) {
-                            if (TAB != 0) r[u].add(V<VEC>::load(tab + c[u] * D + c0));
-                            if (GCN) { acc.fma(wgt[u], r[u]); wacc += wgt[u]; } else acc.add(r[u]);
+                }
+                int pos = beg + cn;
+                while (pos < end) {
+                    if (pos >= cbase + G) {                 // next chunk of the node's pair list (nodes with > G pairs)
+                        cbase += G;
+                        const int idx = cbase + sl;
+                        coff = 0; ctab = 0;
+                        if (idx < end_all) {
+                            coff = (uint32_t)p.col[idx] * xrow_b;
+                            if (TAB != 0) ctab = (uint32_t)p.code[idx] * trow_b;
                         }
                     }
+                    const int lim = min(end, cbase + G) - cbase;
+                    int t = pos - cbase;
+                    for (; t + 1 < lim; t += 2) {
+                        const int l0 = sg_lane0 + t, l1 = l0 + 1;
+                        const uint32_t o0 = __shfl(coff, l0), o1 = __shfl(coff, l1);
+                        uint32_t b0 = 0, b1 = 0;
+                        if (TAB != 0) { b0 = __shfl(ctab, l0); b1 = __shfl(ctab, l1); }
+                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
+                        V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o1 + lane_b)));
+                        if (TAB != 0) {
+                            r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
+                            r1.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b1 + lane_b))));
+                        }
+                        acc.add(r0);
+                        acc.add(r1);
+                    }
+                    if (t < lim) {
+                        const int l0 = sg_lane0 + t;
+                        const uint32_t o0 = __shfl(coff, l0);
+                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
+                        if (TAB != 0) {
+                            const uint32_t b0 = __shfl(ctab, l0);
+                            r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
+                        }
+                        acc.add(r0);
+                    }
+                    pos = cbase + lim;
+                }
+            } else
+            for (int base = beg; base < end; base += G) {
+                const int idx = base + sl;
+                uint32_t myoff = 0, mytab = 0;
+                float myw = 1.0f;
+                if (idx < end) {
+                    const int myj = p.col[idx];
+                    myoff = (uint32_t)myj * xrow_b;
+                    if (TAB != 0) mytab = (uint32_t)p.code[idx] * trow_b;
+                    if (GCN) myw = p.dis[(int64_t)myj * p.K_csr + k];
+                }
+                const int cnt = min(G, end - base);
+                int t = 0;
+                for (; t + 1 < cnt; t += 2) {
+                    const int l0 = sg_lane0 + t, l1 = l0 + 1;
+                    const uint32_t o0 = __shfl(myoff, l0), o1 = __shfl(myoff, l1);
+                    uint32_t b0 = 0, b1 = 0;
+                    if (TAB != 0) { b0 = __shfl(mytab, l0); b1 = __shfl(mytab, l1); }
+                    float w0 = 1.f, w1 = 1.f;
+                    if (GCN) { w0 = __shfl(myw, l0); w1 = __shfl(myw, l1); }
+                    V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
+                    V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o1 + lane_b)));
+                    if (TAB != 0) {
+                        r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
+                        r1.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b1 + lane_b))));
+                    }
+                    if (GCN) { acc.fma(w0, r0); acc.fma(w1, r1); wacc += w0; wacc += w1; }
+                    else { acc.add(r0); acc.add(r1); }
+                }
+                if (t < cnt) {
+                    const int l0 = sg_lane0 + t;
+                    const uint32_t o0 = __shfl(myoff, l0);
+                    V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
+                    if (TAB != 0) {
+                        const uint32_t b0 = __shfl(mytab, l0);
+                        r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
+                    }
+                    if (GCN) { const float w0 = __shfl(myw, l0); acc.fma(w0, r0); wacc += w0; }
+                    else acc.add(r0);
                 }
             }
             const int seglen = end - beg;
@@ -175,7 +293,7 @@ agg_fwd_kernel(const FwdParams p) {
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
             else if (p.uid) {
-                const int u = p.uid[i * p.uid_stride + k];
+                const int u = lane_meta ? uk : p.uid[i * p.uid_stride + k];
                 if (u != last_u) { prow = V<VEC>::load(p.ptab + (int64_t)u * D + c0); last_u = u; }  // mostly one row
                 v.add(prow);
             }
@@ -231,52 +349,130 @@ agg_bwd_kernel(const BwdParams p) {
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
     const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+    const uint32_t grow_b = (uint32_t)p.g_sn * 4u;              // (host: N * g_sn * 4 < 2^32)
+    const uint32_t lane_b = col_ok ? (uint32_t)c0 * 4u : 0u;   // idle lanes re-read column 0 and are dropped below
 
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t j = w.cur * NODES + sg;
         if (j >= p.N) continue;
         const int32_t* rp = p.rowptr + j * p.K_csr;
-        int beg = rp[0];
+        // (as in the forward: row pointers and the node's whole pair list are fetched up front by the sub-group's lanes)
+        const bool lane_meta = G > p.K;
+        int myrp = 0;
+        if (lane_meta) myrp = rp[sl <= p.K ? sl : p.K];
+        int beg = lane_meta ? __shfl(myrp, sg_lane0) : rp[0];
+        const int end_all = lane_meta ? __shfl(myrp, sg_lane0 + p.K) : rp[p.K];
+        constexpr bool CHUNKED = !GCN && TAB == 0;
+        int cbase = beg;
+        uint32_t coff = 0;
+        if (CHUNKED) {
+            const int idx = cbase + sl;
+            if (idx < end_all) coff = (uint32_t)p.col[idx] * grow_b;
+        }
+        constexpr int PF = G >= 32 ? 4 : 2;
+        V<VEC> pr[PF];
+        int prn = 0;
+        auto prefetch = [&](int kk, int bpos, int bend) {      // rows of hop kk's first pairs, requested one hop ahead
+            prn = min(PF, min(bend, cbase + G) - bpos);
+            if (prn < 0) prn = 0;
+            const char* gb = reinterpret_cast<const char*>(p.g + (int64_t)kk * p.g_sk);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (u < prn) {
+                    const uint32_t o = __shfl(coff, sg_lane0 + (bpos - cbase) + u);
+                    pr[u] = V<VEC>::load(reinterpret_cast<const float*>(gb + (size_t)(o + lane_b)));
+                }
+            }
+        };
+        int end_next = lane_meta ? __shfl(myrp, sg_lane0 + 1) : rp[1];
+        if (CHUNKED) prefetch(0, beg, end_next);
         for (int k = 0; k < p.K; ++k) {
-            const int end = rp[k + 1];
+            const int end = end_next;
+            if (k + 1 < p.K) end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
             const float* gk = p.g + (int64_t)k * p.g_sk + c0;
             float* gt = k == 0 ? gt0 : gtk;
             const float dj = GCN ? p.dis[j * p.K_csr + k] : 1.0f;
             V<VEC> acc = V<VEC>::zero();
+            // (same pair walk as the forward: per-pair byte offsets are made once per fetched entry, the gather loop
+            //  broadcasts them and adds the lane's column offset)
+            const char* gkb = reinterpret_cast<const char*>(p.g + (int64_t)k * p.g_sk);   // wave-uniform
+            if (CHUNKED) {
+                V<VEC> cur[PF];
+                const int cn = prn;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) cur[u] = pr[u];
+                if (k + 1 < p.K) prefetch(k + 1, end, end_next);
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+                    if (u < cn) acc.add(cur[u]);
+                int pos = beg + cn;
+                while (pos < end) {
+                    if (pos >= cbase + G) {
+                        cbase += G;
+                        const int idx = cbase + sl;
+                        coff = 0;
+                        if (idx < end_all) coff = (uint32_t)p.col[idx] * grow_b;
+                    }
+                    const int lim = min(end, cbase + G) - cbase;
+                    int t = pos - cbase;
+                    for (; t + 1 < lim; t += 2) {
+                        const int l0 = sg_lane0 + t, l1 = l0 + 1;
+                        const uint32_t o0 = __shfl(coff, l0), o1 = __shfl(coff, l1);
+                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b)));
+                        V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o1 + lane_b)));
+                        acc.add(r0);
+                        acc.add(r1);
+                    }
+                    if (t < lim) {
+                        const uint32_t o0 = __shfl(coff, sg_lane0 + t);
+                        acc.add(V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b))));
+                    }
+                    pos = cbase + lim;
+                }
+            } else
             for (int base = beg; base < end; base += G) {
                 const int idx = base + sl;
-                int myi = 0, myc = 0;
-                if (idx < end) {
-                    myi = p.col[idx];
-                    if (TAB != 0) myc = p.code[idx];
-                }
+                uint32_t myoff = 0;
+                int myc = 0;
                 float myw = 1.0f;
-                if (GCN && idx < end) myw = dj * p.dis[(int64_t)myi * p.K_csr + k];
+                if (idx < end) {
+                    const int myi = p.col[idx];
+                    myoff = (uint32_t)myi * grow_b;
+                    if (TAB != 0) myc = p.code[idx];
+                    if (GCN) myw = dj * p.dis[(int64_t)myi * p.K_csr + k];
+                }
                 const int cnt = min(G, end - base);
-                for (int t = 0; t < cnt; t += 4) {
-                    int ii[4], c[4]; float wgt[4]; V<VEC> r[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int srcl = sg_lane0 + min(t + u, cnt - 1);
-                        ii[u] = __shfl(myi, srcl);
-                        if (TAB != 0) c[u] = __shfl(myc, srcl);
-                        if (GCN) wgt[u] = __shfl(myw, srcl);
+                int t = 0;
+                for (; t + 1 < cnt; t += 2) {
+                    const int l0 = sg_lane0 + t, l1 = l0 + 1;
+                    const uint32_t o0 = __shfl(myoff, l0), o1 = __shfl(myoff, l1);
+                    V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b)));
+                    V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o1 + lane_b)));
+                    if (GCN) {
+                        const float w0 = __shfl(myw, l0), w1 = __shfl(myw, l1);
+                        for (int q = 0; q < VEC; ++q) { r0.v[q] *= w0; r1.v[q] *= w1; }
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        r[u] = V<VEC>::zero();
-                        if (t + u < cnt && col_ok) r[u] = V<VEC>::load(gk + (int64_t)ii[u] * p.g_sn);
+                    acc.add(r0);
+                    acc.add(r1);
+                    int c0c = 0, c1c = 0;
+                    if (TAB != 0) { c0c = __shfl(myc, l0); c1c = __shfl(myc, l1); }   // (all lanes take part in the shuffle)
+                    if (TAB != 0 && col_ok) {
+                        float* d0 = gt + c0c * D + c0;
+                        float* d1 = gt + c1c * D + c0;
+                        for (int q = 0; q < VEC; ++q) { atomicAdd(d0 + q, r0.v[q]); atomicAdd(d1 + q, r1.v[q]); }
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (t + u < cnt && col_ok) {
-                            if (GCN) { for (int q = 0; q < VEC; ++q) r[u].v[q] *= wgt[u]; }
-                            acc.add(r[u]);
-                            if (TAB != 0) {
-                                float* dst = gt + c[u] * D + c0;
-                                for (int q = 0; q < VEC; ++q) atomicAdd(dst + q, r[u].v[q]);
-                            }
-                        }
+                }
+                if (t < cnt) {
+                    const int l0 = sg_lane0 + t;
+                    const uint32_t o0 = __shfl(myoff, l0);
+                    V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b)));
+                    if (GCN) { const float w0 = __shfl(myw, l0); for (int q = 0; q < VEC; ++q) r0.v[q] *= w0; }
+                    acc.add(r0);
+                    int c0c = 0;
+                    if (TAB != 0) c0c = __shfl(myc, l0);
+                    if (TAB != 0 && col_ok) {
+                        float* d0 = gt + c0c * D + c0;
+                        for (int q = 0; q < VEC; ++q) atomicAdd(d0 + q, r0.v[q]);
                     }
                 }
             }
@@ -446,6 +642,8 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         p.xs[k] = (!d->x && k < d->K) ? d->x_slot[k] : nullptr;
         if (p.xs[k] && (!slot_align || ((uintptr_t)p.xs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.xs[k];
     }
+    if ((uint64_t)d->N * (uint64_t)d->x_sn * 4u >= (1ull << 32))
+        return fail(KPGNN_ELIMIT, "aggregate_fwd: N * x row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->x_sn);
     const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
                              {d->x_sn, d->x ? d->x_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
                               d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
@@ -491,6 +689,8 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         if (p.gxs[k] && (!slot_align || ((uintptr_t)p.gxs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.gxs[k];
     }
     p.acc_mask = d->gx ? 0u : d->accumulate_mask;
+    if ((uint64_t)d->N * (uint64_t)d->g_sn * 4u >= (1ull << 32))
+        return fail(KPGNN_ELIMIT, "aggregate_bwd: N * g row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->g_sn);
     const int vec = pick_vec(d->D, {d->g, d->gx ? (const void*)d->gx : slot_align}, {d->g_sn, d->g_sk, d->gx_sn, d->gx ? d->gx_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_bwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);

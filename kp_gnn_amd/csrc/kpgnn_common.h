@@ -68,7 +68,9 @@ size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int
 // returns e2 = exp(-z*z), which the backward needs for the Gaussian density.
 __device__ __forceinline__ float fast_erf(float z, float* e2_out) {
     const float az = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+    // v_rcp_f32 (1 ulp) - __frcp_rn expands to the 12-instruction correctly-rounded division sequence, which was
+    // ~45 % of the GELU epilogue's VALU work; the A&S formula itself is only good to 5e-7
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
     float poly = 1.061405429f;
     poly = fmaf(poly, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
