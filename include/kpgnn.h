@@ -150,6 +150,9 @@ typedef struct kpgnn_agg_fwd_desc {
      * GNNPlus stacks the previous layers' states into [N,k,H] with torch.cat every layer (models/GNNs.py:413-418);
      * with slots the kernel reads the k states where they are and the copy disappears.  K <= 16. */
     const float* x_slot[16];
+    /* Rows of ptab (0 = unknown).  When given and small, the dictionary and theta are staged in LDS next to the
+     * code tables, so the per-hop epilogue has no dependent global loads left. */
+    int32_t n_dict;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

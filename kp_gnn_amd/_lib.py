@@ -29,7 +29,7 @@ class AggFwdDesc(ctypes.Structure):
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("tile_start", c_vp), ("tile_flag", c_vp), ("num_tiles", c_i32), ("tile_node_cap", c_i32),
         ("tile_pair_cap", c_i32),
-        ("x_slot", c_vp * 16),
+        ("x_slot", c_vp * 16), ("n_dict", c_i32),
     ]
 
 

@@ -74,6 +74,8 @@ struct FwdParams {
     const float* xbias;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     const float* xs[16];        // per-hop inputs (x == NULL)
+    int lds_theta, lds_ptab;    // floats of theta / ptab staged in LDS behind the code tables (TAB == 1), 0 = read from global
+    int dbg;                    // KPGNN_AGG_DEBUG ablation bits (experiments only): 1 every pair reads row 0, 2 no GELU, 4 no pre store
 };
 
 // TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
@@ -85,10 +87,19 @@ agg_fwd_kernel(const FwdParams p) {
     const bool COMBINE = p.combine != 0;
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
     const int D = p.D;
+    const float* thp = p.theta;
+    const float* ptp = p.ptab;
     if (TAB == 1) {
         const int n0 = p.n_code0 * D, nk = p.n_codek * D;
         for (int t = threadIdx.x; t < n0; t += kBlock) lds_tab[t] = p.table0[t];
         for (int t = threadIdx.x; t < nk; t += kBlock) lds_tab[n0 + t] = p.tablek[t];
+        // theta and the peripheral dictionary ride along: the per-hop epilogue then has no dependent global load
+        float* th_l = lds_tab + ((n0 + nk + 3) & ~3);
+        float* pt_l = th_l + ((p.lds_theta + 3) & ~3);
+        for (int t = threadIdx.x; t < p.lds_theta; t += kBlock) th_l[t] = p.theta[t];
+        for (int t = threadIdx.x; t < p.lds_ptab; t += kBlock) pt_l[t] = p.ptab[t];
+        if (p.lds_theta) thp = th_l;
+        if (p.lds_ptab) ptp = pt_l;
         __syncthreads();
     }
     const float* tab0 = TAB == 1 ? lds_tab : p.table0;
@@ -135,6 +146,7 @@ agg_fwd_kernel(const FwdParams p) {
             if (idx < end_all) {
                 coff = (uint32_t)p.col[idx] * xrow_b;
                 if (TAB != 0) ctab = (uint32_t)p.code[idx] * trow_b;
+                if (p.dbg & 1) coff = 0;
             }
         }
         // Rows of the NEXT hop's first pairs are requested before the current hop is summed and finished, so the one
@@ -288,18 +300,18 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if (p.pre) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
-            if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
+            if (p.pre && !(p.dbg & 4)) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if (MODE == KPGNN_MODE_GINPLUS && !(p.dbg & 2)) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
             else if (p.uid) {
                 const int u = lane_meta ? uk : p.uid[i * p.uid_stride + k];
-                if (u != last_u) { prow = V<VEC>::load(p.ptab + (int64_t)u * D + c0); last_u = u; }  // mostly one row
+                if (u != last_u) { prow = V<VEC>::load(ptp + (int64_t)u * D + c0); last_u = u; }  // mostly one row
                 v.add(prow);
             }
             if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
             if (COMBINE) {
-                const V<VEC> th = V<VEC>::load(p.theta + k * D + c0);
+                const V<VEC> th = V<VEC>::load(thp + k * D + c0);
                 for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
             } else {
                 v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
@@ -628,6 +640,16 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
     }
     FwdParams p;
+    p.lds_theta = p.lds_ptab = 0;
+    { const char* e = getenv("KPGNN_AGG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    if (tab == 1) {      // small side tables behind the code tables (keeps >= 4 blocks of 256 threads per CU)
+        lds = (lds + 15) & ~(size_t)15;
+        const size_t cap = 36 * 1024;
+        const size_t th_b = combine ? sizeof(float) * (size_t)d->K * d->D : 0;
+        if (th_b && lds + th_b <= cap) { p.lds_theta = d->K * d->D; lds += (th_b + 15) & ~(size_t)15; }
+        const size_t pt_b = (!d->periph && d->ptab && d->n_dict > 0) ? sizeof(float) * (size_t)d->n_dict * d->D : 0;
+        if (pt_b && lds + pt_b <= cap) { p.lds_ptab = d->n_dict * d->D; lds += (pt_b + 15) & ~(size_t)15; }
+    }
     p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
     p.mode = d->mode; p.combine = combine ? 1 : 0;
     p.rowptr = d->rowptr; p.col = d->col; p.code = d->code; p.dis = d->dis;

@@ -161,6 +161,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
     elif uid is not None:
         d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
+        d.n_dict = ptab.shape[0]
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
     tiles = None
