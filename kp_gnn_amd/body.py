@@ -135,6 +135,31 @@ class FeatureConcatEncoder(nn.Module):
         return self.proj(torch.cat(cols, dim=-1))
 
 
+_component_masks = {}
+
+
+def _projected_tables(enc, gate):
+    """gate * (Emb_c.weight @ proj.weight[:, c*W:(c+1)*W]^T) for every component c of a FeatureConcatEncoder, stacked
+    row-wise: [sum_c n_c, out].  One block-structured GEMM instead of one small GEMM + scale per component: the stacked
+    weights [R, W] are spread to [R, C*W] with a static one-hot mask (row r of component c only fills block c), which
+    keeps the whole encoder at ~5 launches forward and ~7 backward (it was 2C + 3 and ~10C: 0.65 ms of tiny launches
+    per training step with the reference's nine components)."""
+    embs = list(enc.embedding_list)
+    C, W = len(embs), embs[0].embedding_dim
+    if C == 1:
+        return gate * F.linear(embs[0].weight, enc.proj.weight)
+    sizes = tuple(e.num_embeddings for e in embs)
+    dev = embs[0].weight.device
+    key = (sizes, dev)
+    mask = _component_masks.get(key)
+    if mask is None:
+        comp = torch.repeat_interleave(torch.arange(C, device=dev), torch.tensor(sizes, device=dev))
+        mask = _component_masks[key] = F.one_hot(comp, C).to(torch.float32).unsqueeze(-1)      # [R, C, 1]
+    e_all = torch.cat([e.weight for e in embs], dim=0)                                       # [R, W]
+    x = (e_all.unsqueeze(1) * mask).reshape(e_all.shape[0], C * W)
+    return gate * F.linear(x, enc.proj.weight)
+
+
 class BatchNorm(nn.Module):
     """PyG's BatchNorm wrapper: parameters live under `.module` (state_dict key compatibility)."""
 
@@ -240,15 +265,13 @@ class _KHopBody(nn.Module):
         if use_e:
             enc, g = self.peripheral_edge_embedding, self._gate(self.pew)
             T = pea.shape[-2]
-            for c, emb in enumerate(enc.embedding_list):
-                tables.append(g * (emb.weight @ enc.proj.weight[:, c * W:(c + 1) * W].t()))
-                sizes.append(emb.num_embeddings)
+            tables.append(_projected_tables(enc, g))
+            sizes.extend(emb.num_embeddings for emb in enc.embedding_list)
             bias = bias + g * T * enc.proj.bias
         if use_c:
             enc, g = self.peripheral_configuration_embedding, self._gate(self.pcw)
-            for c, emb in enumerate(enc.embedding_list):
-                tables.append(g * (emb.weight @ enc.proj.weight[:, c * W:(c + 1) * W].t()))
-                sizes.append(emb.num_embeddings)
+            tables.append(_projected_tables(enc, g))
+            sizes.extend(emb.num_embeddings for emb in enc.embedding_list)
             bias = bias + g * enc.proj.bias
         idx, col_offset, uidx, uid = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
         table = torch.cat(tables, dim=0)
