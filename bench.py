@@ -103,6 +103,23 @@ def capture_graphs(model, batches, flat_grad):
     return graphs
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the PMC counters.  A process cannot profile itself, so the figure comes
+    from the committed rocprofv3 --pmc passes of this same command (profiles/r01/pmc_traffic.json says how they were
+    collected and corrected) and is only reported when the workload is the one that was profiled; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
+    key = f"{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}"
+    try:
+        with open(path) as fh:
+            j = json.load(fh)
+        if j.get("workload_key") == key and kernel in j.get("kernels", {}):
+            return {"traffic": j["kernels"][kernel]["traffic_bytes_per_launch"],
+                    "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+    except (OSError, ValueError):
+        pass
+    return {}
+
+
 def cpu_baseline(args, state_dict, threads):
     """Oracle (CPU restatement of the reference path) fwd+bwd on a bounded sample of the same workload."""
     from kp_gnn_amd.batch import synthetic_zinc_batch
@@ -281,6 +298,7 @@ def main():
                                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(f["gbps"] / HBM_PEAK_GBPS, 4),
                                    "traffic": None, "launches": f["launches"], "avg_launch_ms": round(f["avg_ms"], 4),
                                    "algorithmic_bytes_per_launch": int(f["bytes_per_launch"])}
+                out["roofline"].update(pmc_traffic(args, "agg_fwd_kernel"))
             out["kernels"] = {k: {"launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                                   "algorithmic_GBps": round(v["gbps"], 1)} for k, v in s.items()}
             g = s.get("agg_bwd")

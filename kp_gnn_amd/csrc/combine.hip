@@ -64,11 +64,17 @@ combine_bwd_kernel(const CbParams p) {
         float ghv[VEC];
         for (int q = 0; q < VEC; ++q) ghv[q] = 0.f;
         if (fused) ldv<VEC>(p.gh + i * D + c0, ghv);
+        // all K rows of S of this node are requested before the first one is used (the stores to g below would
+        // otherwise fence every load behind them: one exposed round trip per hop)
+        float sall[KMAX][VEC];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < p.K) ldv<VEC>(p.pre + (i * p.K + k) * (int64_t)D + c0, sall[k]);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k >= p.K) break;
             float s[VEC], gvv[VEC], gg[VEC], a[VEC];
-            ldv<VEC>(p.pre + (i * p.K + k) * (int64_t)D + c0, s);
+            for (int q = 0; q < VEC; ++q) s[q] = sall[k][q];
             if (fused) {
                 float th[VEC];
                 ldv<VEC>(p.theta + k * D + c0, th);
@@ -123,7 +129,7 @@ combine_bwd_kernel(const CbParams p) {
 
 int cb_grid(int N, int G) {
     const int64_t tiles = ((int64_t)N + (kBlock / G) - 1) / (kBlock / G);
-    int64_t g = (int64_t)device_facts().cu_count * 4;
+    int64_t g = (int64_t)device_facts().cu_count * 6;   // (the 26 KB block-reduction buffer allows 6 blocks per CU)
     if (g > tiles) g = tiles;
     return (int)(g < 1 ? 1 : g);
 }
@@ -163,7 +169,7 @@ using namespace kpgnn;
 
 extern "C" size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D) {
     if (N <= 0 || K < 1 || D < 1) return 0;
-    return sizeof(float) * (size_t)device_facts().cu_count * 4 * K * D;  // upper bound on grid * K * D
+    return sizeof(float) * (size_t)device_facts().cu_count * 6 * K * D;  // upper bound on grid * K * D (cb_grid)
 }
 
 extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t stream) {
