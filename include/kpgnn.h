@@ -251,6 +251,7 @@ typedef struct kpgnn_combine_bwd_desc {
     float* gtheta;              /* device [K,D] (overwritten) or NULL */
     void* workspace;            /* device, >= kpgnn_combine_bwd_workspace_bytes(N,K,D) when gtheta != NULL */
     size_t workspace_bytes;
+    int32_t n_dict;             /* rows of ptab (0 = unknown): small dictionaries are staged in LDS */
 } kpgnn_combine_bwd_desc;
 
 size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D);

@@ -67,7 +67,7 @@ class CombineBwdDesc(ctypes.Structure):
         ("periph", c_vp), ("p_sn", c_i64), ("p_sk", c_i64),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("g", c_vp), ("gv", c_vp), ("gtheta", c_vp),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("n_dict", c_i32),
     ]
 
 

@@ -5,6 +5,7 @@
 // multiply, erf, exp, products, sums, an einsum).  Here one streaming pass reads S once and writes g = dL/dS once:
 // a sub-group of G lanes owns a node, lanes span the D columns 16 B wide, the per-thread theta-gradient partial
 // sums live in registers (KMAX x VEC) and leave through a per-block slab reduced in block order (deterministic).
+#include <cstdlib>
 #include <initializer_list>
 
 #include "kpgnn_common.h"
@@ -39,99 +40,122 @@ struct CbParams {
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     float* g;
     float* gv;
-    float* slab;   // [gridDim.x][K][D] theta-gradient partials, or NULL
+    float* slab;     // [gridDim.x][K][D] theta-gradient partials, or NULL
+    int lds_ptab;    // floats of ptab staged in LDS (0: read from global)
+    int dbg;         // KPGNN_CB_DEBUG ablation bits (experiments only): 1 no uid / dictionary read
 };
 
-template <int VEC, int G, int KMAX>
+// Row streaming: a sub-group of G lanes owns one (node, hop) ROW of S per step and strides over the rows; the grid
+// holds a multiple of K sub-groups, so a sub-group always meets the SAME hop k: its theta row and its theta-gradient
+// partial are VEC registers, and two rows handled by one wave are adjacent in memory (the earlier node-per-sub-group
+// walk touched two 416-byte segments 3.3 KB apart per instruction and ran at half the speed of a copy).
+// UN rows per trip keep UN independent loads in flight per lane; `pre` and `g` never alias.
+template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock)
 combine_bwd_kernel(const CbParams p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [kBlock/G][K][D] for the block reduction
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [lds_ptab] dictionary rows, then [NODES][D] reduction
     constexpr int NODES = kBlock / G;
+    constexpr int UN = 4;
     const int sg = threadIdx.x / G, sl = threadIdx.x % G;
     const int c0 = sl * VEC;
-    const int D = p.D;
+    const int D = p.D, K = p.K;
     const bool col_ok = c0 < D;
     const bool fused = p.theta != nullptr;
     const bool want_gt = p.slab != nullptr;
-    float gt[KMAX][VEC];
+    float* pt_l = lds;
+    float* red = lds + ((p.lds_ptab + 3) & ~3);
+    for (int t = threadIdx.x; t < p.lds_ptab; t += kBlock) pt_l[t] = p.ptab[t];
+    if (p.lds_ptab) __syncthreads();
+    const float* __restrict__ ptp = p.lds_ptab ? pt_l : p.ptab;
+    const float* __restrict__ pre = p.pre;
+    float* __restrict__ gout_p = p.g;
+
+    const int64_t R = (int64_t)p.N * K;
+    const int64_t total_sg = (int64_t)gridDim.x * NODES;            // multiple of K (host)
+    const int64_t r0 = (int64_t)blockIdx.x * NODES + sg;
+    const int k = (int)(r0 % K);
+    const int64_t istep = total_sg / K;
+    float thv[VEC], gt[VEC];
+    for (int q = 0; q < VEC; ++q) { thv[q] = 0.f; gt[q] = 0.f; }
+    if (fused && col_ok) ldv<VEC>(p.theta + k * D + c0, thv);
+    if (col_ok) {
+        int64_t i = r0 / K;
+        for (int64_t r = r0; r < R; r += total_sg * UN) {
+            float s[UN][VEC], gvv[UN][VEC], ghv[UN][VEC], pv[UN][VEC];
+            int u_id[UN];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-        for (int q = 0; q < VEC; ++q) gt[k][q] = 0.f;
-    const int64_t tiles = ((int64_t)p.N + NODES - 1) / NODES;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t i = tile * NODES + sg;
-        if (i >= p.N || !col_ok) continue;
-        float ghv[VEC];
-        for (int q = 0; q < VEC; ++q) ghv[q] = 0.f;
-        if (fused) ldv<VEC>(p.gh + i * D + c0, ghv);
-        // all K rows of S of this node are requested before the first one is used (the stores to g below would
-        // otherwise fence every load behind them: one exposed round trip per hop)
-        float sall[KMAX][VEC];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < p.K) ldv<VEC>(p.pre + (i * p.K + k) * (int64_t)D + c0, sall[k]);
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k >= p.K) break;
-            float s[VEC], gvv[VEC], gg[VEC], a[VEC];
-            for (int q = 0; q < VEC; ++q) s[q] = sall[k][q];
-            if (fused) {
-                float th[VEC];
-                ldv<VEC>(p.theta + k * D + c0, th);
-                for (int q = 0; q < VEC; ++q) gvv[q] = th[q] * ghv[q];
-            } else {
-                ldv<VEC>(p.gout + i * p.go_sn + (int64_t)k * p.go_sk + c0, gvv);
-            }
-            for (int q = 0; q < VEC; ++q) {
-                if (p.mode == KPGNN_MODE_GINPLUS) {
-                    float e2;  // exp(-s^2/2) comes with the erf approximation
-                    const float cdf = 0.5f * (1.0f + fast_erf(s[q] * 0.70710678118654752440f, &e2));
-                    const float pdf = e2 * 0.39894228040143267794f;
-                    a[q] = s[q] * cdf;
-                    gg[q] = gvv[q] * (cdf + s[q] * pdf);
-                } else if (p.mode == KPGNN_MODE_GCN) {
-                    a[q] = fmaxf(s[q], 0.f);
-                    gg[q] = s[q] > 0.f ? gvv[q] : 0.f;
-                } else {
-                    a[q] = s[q];
-                    gg[q] = gvv[q];
+            for (int u = 0; u < UN; ++u) {
+                const int64_t ru = r + u * total_sg, iu = i + u * istep;
+                for (int q = 0; q < VEC; ++q) { s[u][q] = 0.f; gvv[u][q] = 0.f; ghv[u][q] = 0.f; pv[u][q] = 0.f; }
+                u_id[u] = -1;
+                if (ru < R) {
+                    ldv<VEC>(pre + ru * D + c0, s[u]);
+                    if (fused) ldv<VEC>(p.gh + iu * D + c0, ghv[u]);
+                    else ldv<VEC>(p.gout + iu * p.go_sn + (int64_t)k * p.go_sk + c0, gvv[u]);
+                    if (want_gt) {
+                        if (p.periph) ldv<VEC>(p.periph + iu * p.p_sn + (int64_t)k * p.p_sk + c0, pv[u]);
+                        else if (p.uid && !(p.dbg & 1)) u_id[u] = p.uid[iu * p.uid_stride + k];
+                    }
                 }
             }
-            stv<VEC>(p.g + (i * p.K + k) * (int64_t)D + c0, gg);
-            if (p.gv) stv<VEC>(p.gv + (i * p.K + k) * (int64_t)D + c0, gvv);
-            if (want_gt) {
-                float pv[VEC];
-                for (int q = 0; q < VEC; ++q) pv[q] = 0.f;
-                if (p.periph) ldv<VEC>(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0, pv);
-                else if (p.uid) ldv<VEC>(p.ptab + (int64_t)p.uid[i * p.uid_stride + k] * D + c0, pv);
-                for (int q = 0; q < VEC; ++q) gt[k][q] = fmaf(ghv[q], a[q] + pv[q], gt[k][q]);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t ru = r + u * total_sg;
+                if (ru >= R) break;
+                float gg[VEC], a[VEC];
+                if (fused) for (int q = 0; q < VEC; ++q) gvv[u][q] = thv[q] * ghv[u][q];
+                for (int q = 0; q < VEC; ++q) {
+                    const float sv = s[u][q];
+                    if (p.mode == KPGNN_MODE_GINPLUS) {
+                        float e2;  // exp(-s^2/2) comes with the erf approximation
+                        const float cdf = 0.5f * (1.0f + fast_erf(sv * 0.70710678118654752440f, &e2));
+                        const float pdf = e2 * 0.39894228040143267794f;
+                        a[q] = sv * cdf;
+                        gg[q] = gvv[u][q] * (cdf + sv * pdf);
+                    } else if (p.mode == KPGNN_MODE_GCN) {
+                        a[q] = fmaxf(sv, 0.f);
+                        gg[q] = sv > 0.f ? gvv[u][q] : 0.f;
+                    } else {
+                        a[q] = sv;
+                        gg[q] = gvv[u][q];
+                    }
+                }
+                stv<VEC>(gout_p + ru * D + c0, gg);
+                if (p.gv) stv<VEC>(p.gv + ru * D + c0, gvv[u]);
+                if (want_gt) {
+                    if (u_id[u] >= 0) ldv<VEC>(ptp + (int64_t)u_id[u] * D + c0, pv[u]);
+                    for (int q = 0; q < VEC; ++q) gt[q] = fmaf(ghv[u][q], a[q] + pv[u][q], gt[q]);
+                }
             }
+            i += istep * UN;
         }
     }
     if (!want_gt) return;
-    // block reduction over the sub-groups (same columns), then one slab row per block
-    float* mine = red + (size_t)sg * p.K * D;
-    if (col_ok) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k >= p.K) break;
-            for (int q = 0; q < VEC; ++q) mine[k * D + c0 + q] = gt[k][q];
-        }
-    }
+    // per-block theta-gradient partial: sub-groups of the block that met hop k2 are added in sub-group order
+    if (col_ok) for (int q = 0; q < VEC; ++q) red[sg * D + c0 + q] = gt[q];
     __syncthreads();
-    float* out = p.slab + (size_t)blockIdx.x * p.K * D;
-    for (int e = threadIdx.x; e < p.K * D; e += kBlock) {
+    float* out = p.slab + (size_t)blockIdx.x * K * D;
+    for (int e = threadIdx.x; e < K * D; e += kBlock) {
+        const int k2 = e / D, dcol = e - k2 * D;
         float tot = 0.f;
-        for (int s2 = 0; s2 < NODES; ++s2) tot += red[(size_t)s2 * p.K * D + e];
+        for (int s2 = 0; s2 < NODES; ++s2)
+            if ((int)(((int64_t)blockIdx.x * NODES + s2) % K) == k2) tot += red[s2 * D + dcol];
         out[e] = tot;
     }
 }
 
-int cb_grid(int N, int G) {
-    const int64_t tiles = ((int64_t)N + (kBlock / G) - 1) / (kBlock / G);
-    int64_t g = (int64_t)device_facts().cu_count * 6;   // (the 26 KB block-reduction buffer allows 6 blocks per CU)
-    if (g > tiles) g = tiles;
-    return (int)(g < 1 ? 1 : g);
+// grid: <= 8 blocks per CU, (grid * sub-groups per block) a multiple of K
+int cb_grid(int N, int K, int G) {
+    const int nodes = kBlock / G;
+    const int64_t rows = (int64_t)N * K;
+    int64_t g = (int64_t)device_facts().cu_count * 8;
+    const int64_t need = (rows + nodes - 1) / nodes;
+    if (g > need) g = need;
+    // smallest m with (m * nodes) % K == 0
+    int m = 1;
+    while ((m * nodes) % K) ++m;
+    g = ((g + m - 1) / m) * m;
+    return (int)(g < m ? m : g);
 }
 
 int cb_shape(const kpgnn_combine_bwd_desc* d, int* vec, int* g) {
@@ -150,14 +174,9 @@ int cb_shape(const kpgnn_combine_bwd_desc* d, int* vec, int* g) {
 
 template <int VEC, int G>
 int cb_launch(const CbParams& p, int grid, hipStream_t s) {
-    const size_t lds = p.slab ? sizeof(float) * (size_t)(kBlock / G) * p.K * p.D : 0;
-    if (p.K <= 8) {
-        if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, 8>, lds));
-        hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, 8>), dim3(grid), dim3(kBlock), lds, s, p);
-    } else {
-        if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, 16>, lds));
-        hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, 16>), dim3(grid), dim3(kBlock), lds, s, p);
-    }
+    const size_t lds = sizeof(float) * (size_t)(((p.lds_ptab + 3) & ~3) + (p.slab ? (kBlock / G) * p.D : 0));
+    if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G>, lds));
+    hipLaunchKernelGGL((combine_bwd_kernel<VEC, G>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("combine_bwd_kernel");
     return KPGNN_OK;
 }
@@ -169,7 +188,7 @@ using namespace kpgnn;
 
 extern "C" size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D) {
     if (N <= 0 || K < 1 || D < 1) return 0;
-    return sizeof(float) * (size_t)device_facts().cu_count * 6 * K * D;  // upper bound on grid * K * D (cb_grid)
+    return sizeof(float) * ((size_t)device_facts().cu_count * 8 + 16) * K * D;  // upper bound on grid * K * D (cb_grid)
 }
 
 extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t stream) {
@@ -188,14 +207,15 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     p.gout = d->gout; p.go_sn = d->go_sn; p.go_sk = d->go_sk; p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     p.g = d->g; p.gv = d->gv; p.slab = nullptr;
-    const int grid = cb_grid(d->N, g);
+    const int grid = cb_grid(d->N, d->K, g);
+    p.lds_ptab = 0;
+    { const char* e = getenv("KPGNN_CB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     if (d->gtheta) {
         const size_t need = sizeof(float) * (size_t)grid * d->K * d->D;
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= need, "combine_bwd: workspace too small (%zu < %zu)",
                       (size_t)d->workspace_bytes, need);
-        const size_t lds = sizeof(float) * (size_t)(kBlock / g) * d->K * d->D;
-        if (lds > 160 * 1024) return fail(KPGNN_ELIMIT, "combine_bwd: theta-gradient reduction needs %zu B of LDS", lds);
         p.slab = (float*)d->workspace;
+        if (p.ptab && p.uid && d->n_dict > 0 && (size_t)d->n_dict * d->D * sizeof(float) <= 16 * 1024) p.lds_ptab = d->n_dict * d->D;
     }
     hipStream_t s = (hipStream_t)stream;
 #define KP_CB(V, GG) rc = cb_launch<V, GG>(p, grid, s); break

@@ -330,6 +330,7 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
     elif uid is not None and ptab is not None:  # (P is only read for the theta gradient)
         d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
+        d.n_dict = ptab.shape[0]
     g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
     gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
     gth = torch.empty((K, D), dtype=torch.float32, device=dev) if want_gtheta else None
