@@ -222,6 +222,9 @@ typedef struct kpgnn_table_grad_desc {
     const float* fuse_ptab;     /* device [n_dict, D] or NULL */
     float* gtheta;              /* device [K, D] (output) or NULL */
     int32_t fuse_mode;          /* KPGNN_MODE_* */
+    /* Longest (node, hop) segment of the CSR, or 0 when unknown.  1..256 allows the wide-row kernel that runs the count
+     * matrix product on the bf16 matrix cores (g split exactly into three bf16 parts; counts must be exact in bf16). */
+    int32_t max_pairs_per_segment;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,

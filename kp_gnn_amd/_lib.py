@@ -56,6 +56,7 @@ class TableGradDesc(ctypes.Structure):
         ("gtable0", c_vp), ("gtablek", c_vp), ("gdict", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("fuse_pre", c_vp), ("fuse_g", c_vp), ("fuse_ptab", c_vp), ("gtheta", c_vp), ("fuse_mode", c_i32),
+        ("max_pairs_per_segment", c_i32),
     ]
 
 

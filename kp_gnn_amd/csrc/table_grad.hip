@@ -386,10 +386,19 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
         // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
         // dictionary rows) at D = 13.  Wide rows stay on the register walk (D = 104: 78 vs 121 us; the 16x16x4 product
-        // is matrix-core bound there).  KPGNN_TG_KERNEL=walk|mfma forces one of them.
-        static const int force = [] { const char* e = getenv("KPGNN_TG_KERNEL");
-                                      return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+        // is matrix-core bound there).  KPGNN_TG_KERNEL=walk|mfma|bf16 forces one of them.
+        const char* fe = getenv("KPGNN_TG_KERNEL");          // read per call: the parity tests flip it
+        const int force = !fe ? 0 : (fe[0] == 'w' ? 1 : (fe[0] == 'm' ? 2 : (fe[0] == 'b' ? 3 : 0)));
         const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows;
+        // wide rows, opt-in (KPGNN_TG_KERNEL=bf16): count matrix x (g split exactly into three bf16 parts) on the bf16
+        // matrix cores, when the caller vouches that no segment holds more than 256 pairs (counts stay exact in bf16).
+        // Measured 112 us against the walk's 105 us over the bench's k = 1..8 mix (85 vs 98 us at k = 8 with unsorted
+        // dictionary ids): the three-part product is matrix-core bound and its phases do not overlap the g stream.
+        if (force == 3 && d->D > 32 && d->max_pairs_per_segment >= 1 && d->max_pairs_per_segment <= 256) {
+            bool handled = false;
+            const int rc = table_grad_bf16(d, s, &handled);
+            if (rc != KPGNN_OK || handled) return rc;
+        }
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);

@@ -22,7 +22,7 @@ class KHopCSR:
     """int32 CSR by (dst,hop) and by (src,hop) of the active (edge,hop) pairs."""
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
-                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs", "_ctiles",
+                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "max_seg_pairs", "_dis", "_apairs", "_ctiles",
                  "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
@@ -124,6 +124,8 @@ class KHopCSR:
                                            c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr(),
                                            c.nodes_per_tile, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(),
                                            ws.data_ptr(), ctypes.c_size_t(ws.numel()), stream), "kpgnn_csr_build")
+            # longest (node, hop) segment: the bf16 table-gradient kernel needs pair counts <= 256 (exact in bf16)
+            c.max_seg_pairs = int((c.rowptr_dst[1:] - c.rowptr_dst[:-1]).max()) if S > 0 else 0
         return c
 
 

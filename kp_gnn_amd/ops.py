@@ -286,6 +286,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     else:
         d.g = g.data_ptr()
     d.g_sn, d.g_sk = K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
+    d.max_pairs_per_segment = int(getattr(csr, "max_seg_pairs", 0) or 0) if edges else 1
     gt0 = gtk = gd = None
     if edges:
         gt0 = torch.empty((n0, D), dtype=torch.float32, device=dev)

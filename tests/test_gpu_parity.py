@@ -747,3 +747,43 @@ def test_geo_theta_kernel_vs_reference_formula(K, D):
     # the module's own forward (KP-GIN attention-free path) uses the same weights
     x = torch.randn(50, K, D, generator=g)
     _close(m(x.to(dev)), ref_m(x), "combine", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kernel", ["walk", "mfma", "bf16"])
+@pytest.mark.parametrize("D,dict_mode", [(104, "theta_gh"), (104, "rows"), (40, "none"), (13, "rows"), (64, "theta_gh")])
+def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode, monkeypatch):
+    """The three table-gradient kernels (register walk, fp32 count-matrix MFMA, exact bf16x3 count-matrix MFMA) against
+    torch index_add_ on the same (code, row) pairs: edge-code tables and both dictionary sources."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    monkeypatch.setenv("KPGNN_TG_KERNEL", kernel)
+    g0 = torch.Generator().manual_seed(D * 7 + len(dict_mode))
+    N, K, E = 333, 8, 6000
+    ei = torch.randint(0, N, (2, E), generator=g0)
+    ea = torch.randint(0, 6, (E, K), generator=g0) * (torch.rand(E, K, generator=g0) < 0.4)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    gt = torch.randn(N, K, D, generator=g0)
+    U = 19
+    uid = torch.randint(0, U, (N, K), generator=g0, dtype=torch.int32)
+    theta = torch.rand(K, D, generator=g0)
+    gh = torch.randn(N, D, generator=g0)
+    kw = {}
+    if dict_mode == "theta_gh":
+        kw = dict(uid=uid.to(dev), n_dict=U, theta=theta.to(dev), gh=gh.to(dev))
+    elif dict_mode == "rows":
+        kw = dict(uid=uid.to(dev), n_dict=U)
+    res = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **kw)
+    assert res is not None
+    gt0, gtk, gd = res
+    e, k = torch.nonzero(ea, as_tuple=True)
+    rows = gt[ei[1][e], k]                      # g of the destination segment of every active pair
+    code = ea[e, k]
+    ref0 = torch.zeros(6, D).index_add_(0, code[k == 0], rows[k == 0])
+    refk = torch.zeros(6, D).index_add_(0, code[k > 0], rows[k > 0])
+    _close(gt0, ref0, "gtable0", rtol=2e-4, atol=2e-5)
+    _close(gtk, refk, "gtablek", rtol=2e-4, atol=2e-5)
+    if dict_mode != "none":
+        src = (theta.unsqueeze(0) * gh.unsqueeze(1)) if dict_mode == "theta_gh" else gt
+        refd = torch.zeros(U, D).index_add_(0, uid.reshape(-1).long(), src.reshape(-1, D))
+        _close(gd, refd, "gdict", rtol=2e-4, atol=2e-5)
