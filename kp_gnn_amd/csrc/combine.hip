@@ -50,18 +50,21 @@ struct CbParams {
 // partial are VEC registers, and two rows handled by one wave are adjacent in memory (the earlier node-per-sub-group
 // walk touched two 416-byte segments 3.3 KB apart per instruction and ran at half the speed of a copy).
 // UN rows per trip keep UN independent loads in flight per lane; `pre` and `g` never alias.
-template <int VEC, int G>
+// ACT: 1 = GELU (KP-GIN+), 2 = ReLU (KP-GCN), 0 = none; WGT: theta gradient wanted.  Compile-time so that the
+// per-element arithmetic is straight-line code (as runtime switches it was a chain of uniform branches per element
+// that kept the VALU from overlapping the four rows in flight).
+template <int VEC, int G, int ACT, bool WGT>
 __global__ void __launch_bounds__(kBlock)
 combine_bwd_kernel(const CbParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [lds_ptab] dictionary rows, then [NODES][D] reduction
     constexpr int NODES = kBlock / G;
-    constexpr int UN = 4;
+    constexpr int UN = WGT ? 2 : 4;   // (the theta-gradient path keeps ghv / pv / a alive per row: 158 VGPRs at 4 rows)
     const int sg = threadIdx.x / G, sl = threadIdx.x % G;
     const int c0 = sl * VEC;
     const int D = p.D, K = p.K;
     const bool col_ok = c0 < D;
     const bool fused = p.theta != nullptr;
-    const bool want_gt = p.slab != nullptr;
+    constexpr bool want_gt = WGT;
     float* pt_l = lds;
     float* red = lds + ((p.lds_ptab + 3) & ~3);
     for (int t = threadIdx.x; t < p.lds_ptab; t += kBlock) pt_l[t] = p.ptab[t];
@@ -79,6 +82,8 @@ combine_bwd_kernel(const CbParams p) {
     for (int q = 0; q < VEC; ++q) { thv[q] = 0.f; gt[q] = 0.f; }
     if (fused && col_ok) ldv<VEC>(p.theta + k * D + c0, thv);
     if (col_ok) {
+        // (explicit double buffering of the row loads was tried: 160 vs 114 us - the second register set costs a wave
+        //  per SIMD; UN independent rows per trip with one set is the better trade)
         int64_t i = r0 / K;
         for (int64_t r = r0; r < R; r += total_sg * UN) {
             float s[UN][VEC], gvv[UN][VEC], ghv[UN][VEC], pv[UN][VEC];
@@ -106,13 +111,13 @@ combine_bwd_kernel(const CbParams p) {
                 if (fused) for (int q = 0; q < VEC; ++q) gvv[u][q] = thv[q] * ghv[u][q];
                 for (int q = 0; q < VEC; ++q) {
                     const float sv = s[u][q];
-                    if (p.mode == KPGNN_MODE_GINPLUS) {
+                    if (ACT == 1) {
                         float e2;  // exp(-s^2/2) comes with the erf approximation
                         const float cdf = 0.5f * (1.0f + fast_erf(sv * 0.70710678118654752440f, &e2));
                         const float pdf = e2 * 0.39894228040143267794f;
                         a[q] = sv * cdf;
                         gg[q] = gvv[u][q] * (cdf + sv * pdf);
-                    } else if (p.mode == KPGNN_MODE_GCN) {
+                    } else if (ACT == 2) {
                         a[q] = fmaxf(sv, 0.f);
                         gg[q] = sv > 0.f ? gvv[u][q] : 0.f;
                     } else {
@@ -124,23 +129,30 @@ combine_bwd_kernel(const CbParams p) {
                 if (p.gv) stv<VEC>(p.gv + ru * D + c0, gvv[u]);
                 if (want_gt) {
                     if (u_id[u] >= 0) ldv<VEC>(ptp + (int64_t)u_id[u] * D + c0, pv[u]);
-                    for (int q = 0; q < VEC; ++q) gt[q] = fmaf(ghv[u][q], a[q] + pv[u][q], gt[q]);
+                    if (!(p.dbg & 2)) for (int q = 0; q < VEC; ++q) gt[q] = fmaf(ghv[u][q], a[q] + pv[u][q], gt[q]);
                 }
             }
             i += istep * UN;
         }
     }
-    if (!want_gt) return;
+    if (!want_gt || (p.dbg & 4)) return;
     // per-block theta-gradient partial: sub-groups of the block that met hop k2 are added in sub-group order
     if (col_ok) for (int q = 0; q < VEC; ++q) red[sg * D + c0 + q] = gt[q];
     __syncthreads();
+    // (hop of sub-group s2 = (kb0 + s2) mod K: walked in sub-group order, no per-element division / 64-bit modulo -
+    //  the earlier form of this tail cost ~15 us of a 150 us launch)
     float* out = p.slab + (size_t)blockIdx.x * K * D;
-    for (int e = threadIdx.x; e < K * D; e += kBlock) {
-        const int k2 = e / D, dcol = e - k2 * D;
-        float tot = 0.f;
-        for (int s2 = 0; s2 < NODES; ++s2)
-            if ((int)(((int64_t)blockIdx.x * NODES + s2) % K) == k2) tot += red[s2 * D + dcol];
-        out[e] = tot;
+    const int kb0 = (int)(((int64_t)blockIdx.x * NODES) % K);
+    for (int dcol = threadIdx.x; dcol < D; dcol += kBlock) {
+        for (int k2 = 0; k2 < K; ++k2) {
+            float tot = 0.f;
+            int kk = kb0;
+            for (int s2 = 0; s2 < NODES; ++s2) {
+                if (kk == k2) tot += red[s2 * D + dcol];
+                if (++kk == K) kk = 0;
+            }
+            out[k2 * D + dcol] = tot;
+        }
     }
 }
 
@@ -172,13 +184,26 @@ int cb_shape(const kpgnn_combine_bwd_desc* d, int* vec, int* g) {
     return KPGNN_OK;
 }
 
+template <int VEC, int G, int ACT, bool WGT>
+int cb_launch2(const CbParams& p, int grid, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, ACT, WGT>, lds));
+    hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, ACT, WGT>), dim3(grid), dim3(kBlock), lds, s, p);
+    KPGNN_LAUNCH_CHECK("combine_bwd_kernel");
+    return KPGNN_OK;
+}
+
 template <int VEC, int G>
 int cb_launch(const CbParams& p, int grid, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)(((p.lds_ptab + 3) & ~3) + (p.slab ? (kBlock / G) * p.D : 0));
-    if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G>, lds));
-    hipLaunchKernelGGL((combine_bwd_kernel<VEC, G>), dim3(grid), dim3(kBlock), lds, s, p);
-    KPGNN_LAUNCH_CHECK("combine_bwd_kernel");
-    return KPGNN_OK;
+    const int act = p.mode == KPGNN_MODE_GINPLUS ? 1 : (p.mode == KPGNN_MODE_GCN ? 2 : 0);
+    if (p.slab) {
+        if (act == 1) return cb_launch2<VEC, G, 1, true>(p, grid, lds, s);
+        if (act == 2) return cb_launch2<VEC, G, 2, true>(p, grid, lds, s);
+        return cb_launch2<VEC, G, 0, true>(p, grid, lds, s);
+    }
+    if (act == 1) return cb_launch2<VEC, G, 1, false>(p, grid, lds, s);
+    if (act == 2) return cb_launch2<VEC, G, 2, false>(p, grid, lds, s);
+    return cb_launch2<VEC, G, 0, false>(p, grid, lds, s);
 }
 
 }  // namespace

@@ -24,6 +24,9 @@ for name, mode in (("GINPLUS (erf)", _lib.MODE_GINPLUS), ("GCN (relu)", _lib.MOD
         print(f"{name:14s} gtheta={gt}: {t:.0f} us", flush=True)
 os.environ["KPGNN_CB_DEBUG"] = "1"
 print("GINPLUS gtheta, no uid/dictionary read:", round(timeit(lambda: ops.combine_bwd_raw(_lib.MODE_GINPLUS, pre, gh, theta, None, ptab, uid, want_gtheta=True, want_gv=False))), "us")
+for dbg in (2, 4, 6, 7):
+    os.environ["KPGNN_CB_DEBUG"] = str(dbg)
+    print(f"GINPLUS gtheta dbg={dbg}:", round(timeit(lambda: ops.combine_bwd_raw(_lib.MODE_GINPLUS, pre, gh, theta, None, ptab, uid, want_gtheta=True, want_gv=False))), "us")
 os.environ["KPGNN_CB_DEBUG"] = "0"
 print("GINPLUS gtheta, dense P:", round(timeit(lambda: ops.combine_bwd_raw(_lib.MODE_GINPLUS, pre, gh, theta, pre, None, None, want_gtheta=True, want_gv=False))), "us")
 print("clone [N,K,D]:", round(timeit(lambda: pre.clone())), "us")
