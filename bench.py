@@ -218,10 +218,12 @@ def main():
             f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]})")
 
     model = build_model(args, device)
-    flat_grad = dp.flatten_grads(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
     if world > 1:  # identical replicas
         dp.broadcast_model(model)
+    flat_grad = dp.flatten_grads(model)
+    flat_param = dp.flatten_params(model)     # parameters and gradients: one flat bucket each (same order)
+    flat_param.grad = flat_grad
+    opt = torch.optim.Adam([flat_param], lr=1e-3, fused=True, capturable=True)   # elementwise: identical to per-parameter Adam
 
     def barrier():
         torch.cuda.synchronize()

@@ -7,15 +7,41 @@ import torch
 import torch.distributed as dist
 
 
+_ALIGN = 64   # floats: every tensor of a flat bucket starts on a 256-byte boundary (the kernels' 16-B vector paths)
+
+
+def _offsets(params):
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    return offs, off
+
+
 def flatten_grads(model):
     """Make every parameter's .grad a view of one flat fp32 buffer; returns the buffer."""
     params = [p for p in model.parameters() if p.requires_grad]
-    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
-    off = 0
-    for p in params:
+    offs, total = _offsets(params)
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    for p, off in zip(params, offs):
         p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
     return flat
+
+
+def flatten_params(model):
+    """Re-home every trainable parameter as a view of ONE flat fp32 buffer (same order as flatten_grads) and return
+    it as an nn.Parameter: an elementwise optimiser (Adam, SGD) stepping that single tensor updates all of them with
+    one multi-tensor launch instead of one chunk list per ~190 parameters; module attributes, state_dict keys and
+    the captured graphs (which hold the views) are unaffected."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    offs, total = _offsets(params)
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    with torch.no_grad():
+        for p, off in zip(params, offs):
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view_as(p)
+    return torch.nn.Parameter(flat)
 
 
 def grad_views(model):

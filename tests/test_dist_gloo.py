@@ -64,3 +64,35 @@ def test_flat_bucket_allreduce_world2():
     assert res["mean_ok"] and res["replicas_equal"] and res["views"]
     assert res["tmax"] == 2.0
     assert len(set(res["seeds"])) == 8 and min(b - a for a, b in zip(res["seeds"], res["seeds"][1:])) == 64
+
+
+def test_flat_parameter_bucket_steps_like_per_parameter_adam():
+    """dp.flatten_params / flatten_grads: Adam on the single flat (256-B aligned, zero-padded) bucket takes exactly the
+    steps of Adam on the individual parameters, and the module keeps seeing its parameters through the views."""
+    import copy
+    import torch
+    from kp_gnn_amd import dp
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 5), torch.nn.Linear(5, 1))
+    mod = copy.deepcopy(ref)
+    flat_g = dp.flatten_grads(mod)
+    flat_p = dp.flatten_params(mod)
+    flat_p.grad = flat_g
+    assert all(p.data_ptr() % 256 == flat_p.data_ptr() % 256 for p in mod.parameters())
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    opt = torch.optim.Adam([flat_p], lr=1e-2)
+    for step in range(4):
+        x = torch.randn(32, 7)
+        for m, o in ((ref, opt_ref), (mod, opt)):
+            loss = m(x).pow(2).mean()
+            if m is ref:
+                o.zero_grad()
+                loss.backward()
+            else:
+                params, views = dp.grad_views(m)
+                grads = torch.autograd.grad(loss, params)
+                torch._foreach_copy_(views, list(grads))
+            o.step()
+    for a, b in zip(ref.parameters(), mod.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert set(ref.state_dict()) == set(mod.state_dict())
