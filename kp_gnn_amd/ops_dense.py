@@ -2,6 +2,7 @@
 
 The nn.BatchNorm1d modules stay where the reference has them (state_dict keys `mlp.1.*`, `norms.l.module.*`);
 only their training-mode arithmetic is routed here.  Eval mode (running statistics) uses torch's own GPU op."""
+import contextlib
 import ctypes
 
 import torch
@@ -131,17 +132,47 @@ class LinearWgrad(torch.autograd.Function):
             dx = _mfma_linear(dy, weight.t().contiguous(), None) if _USE_MFMA_LINEAR else None
             if dx is None:
                 dx = dy @ weight
-        dw = torch.empty((O, I), dtype=torch.float32, device=dev)
-        db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-        nb = lib.kpgnn_wgrad_workspace_bytes(O, I)
-        ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
-        d = _lib.WgradDesc()
-        d.N, d.O, d.I = N, O, I
-        d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
-        d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
-        with torch.cuda.device(dev):
-            _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(d), _stream(dy)), "kpgnn_linear_wgrad")
+        # Weight gradients are leaves of the backward graph: nothing downstream waits for them until the optimiser.
+        # With overlap enabled (set_wgrad_overlap; the caller then owes a join_wgrad_stream() before it touches any
+        # .grad) the 1-block-per-CU MFMA kernel runs on a side stream next to the main stream's streaming kernels.
+        side = None
+        if _wgrad_overlap["on"]:
+            from .ops import _side_stream
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            dw = torch.empty((O, I), dtype=torch.float32, device=dev)
+            db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+            nb = lib.kpgnn_wgrad_workspace_bytes(O, I)
+            ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+            d = _lib.WgradDesc()
+            d.N, d.O, d.I = N, O, I
+            d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+            d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
+            with torch.cuda.device(dev):
+                _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(d), _stream(dy)), "kpgnn_linear_wgrad")
+        if side is not None:
+            _wgrad_overlap["pending"].append((dev, dy, x, ws))   # keep the operands alive until the join
         return dx, dw, db
+
+
+_wgrad_overlap = {"on": False, "pending": []}
+
+
+def set_wgrad_overlap(flag):
+    """Opt in to running the weight-gradient kernels on a side stream.  The caller must call join_wgrad_stream()
+    after backward and before reading or stepping any gradient (bench.py does, inside the captured graph)."""
+    _wgrad_overlap["on"] = bool(flag)
+
+
+def join_wgrad_stream():
+    pend = _wgrad_overlap["pending"]
+    if pend:
+        from .ops import _side_stream
+        for dev in {p[0] for p in pend}:
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        pend.clear()
 
 
 def linear(x, lin):
