@@ -80,11 +80,13 @@ struct FwdParams {
 
 // TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
 // GCN selects the weighted inner loop; the other epilogues are wave-uniform runtime switches.
-template <int VEC, int G, bool GCN, int TAB>
+// FAST: the KP-GIN+ training configuration (GELU epilogue, fused geometric combine, dictionary P, S saved) with its
+// epilogue switches resolved at compile time.
+template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
 __global__ void __launch_bounds__(kBlock)
 agg_fwd_kernel(const FwdParams p) {
-    const int MODE = p.mode;
-    const bool COMBINE = p.combine != 0;
+    const int MODE = FAST ? (int)KPGNN_MODE_GINPLUS : p.mode;
+    const bool COMBINE = FAST ? true : p.combine != 0;
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
     const int D = p.D;
     const float* thp = p.theta;
@@ -134,7 +136,7 @@ agg_fwd_kernel(const FwdParams p) {
         int myrp = 0, myuid = 0;
         if (lane_meta) {
             myrp = rp[sl <= p.K ? sl : p.K];
-            if (p.uid && !p.periph) myuid = p.uid[i * p.uid_stride + (sl < p.K ? sl : 0)];
+            if (FAST || (p.uid && !p.periph)) myuid = p.uid[i * p.uid_stride + (sl < p.K ? sl : 0)];
         }
         int beg = lane_meta ? __shfl(myrp, sg_lane0) : rp[0];
         const int end_all = lane_meta ? __shfl(myrp, sg_lane0 + p.K) : rp[p.K];
@@ -300,11 +302,11 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if (p.pre && !(p.dbg & 4)) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if ((FAST || p.pre) && !(p.dbg & 4)) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
             if (MODE == KPGNN_MODE_GINPLUS && !(p.dbg & 2)) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
-            if (p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
-            else if (p.uid) {
+            if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
+            else if (FAST || p.uid) {
                 const int u = lane_meta ? uk : p.uid[i * p.uid_stride + k];
                 if (u != last_u) { prow = V<VEC>::load(ptp + (int64_t)u * D + c0); last_u = u; }  // mostly one row
                 v.add(prow);
@@ -547,13 +549,13 @@ unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
     return (unsigned)(g > 0 ? g : 1);
 }
 
-template <int VEC, int G, bool GCN, int TAB>
+template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
 int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     const unsigned grid = pick_grid(tiles, 8);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB>, lds));
-    hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds));
+    hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB, FAST>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
     return KPGNN_OK;
 }
@@ -563,7 +565,11 @@ int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
     const bool gcn = p.mode == KPGNN_MODE_GCN;
     switch (tab) {
         case 0: return gcn ? launch_fwd<VEC, G, true, 0>(p, 0, s) : launch_fwd<VEC, G, false, 0>(p, 0, s);
-        case 1: return gcn ? launch_fwd<VEC, G, true, 1>(p, lds, s) : launch_fwd<VEC, G, false, 1>(p, lds, s);
+        case 1: {
+            if (gcn) return launch_fwd<VEC, G, true, 1>(p, lds, s);
+            const bool fast = p.mode == KPGNN_MODE_GINPLUS && p.combine && !p.periph && p.uid && p.ptab && p.pre && !p.dbg;
+            return fast ? launch_fwd<VEC, G, false, 1, true>(p, lds, s) : launch_fwd<VEC, G, false, 1>(p, lds, s);
+        }
         default: return gcn ? launch_fwd<VEC, G, true, 2>(p, 0, s) : launch_fwd<VEC, G, false, 2>(p, 0, s);
     }
 }
