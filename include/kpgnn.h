@@ -360,6 +360,7 @@ typedef struct kpgnn_linear_desc {
     const float* w;                       /* device [O,I] contiguous */
     const float* bias;                    /* device [O] or NULL */
     float* y; int64_t y_stride;           /* device [N,O] */
+    int32_t w_transposed;                 /* 1: w is [I,O] (y = x w): dx = dy W needs no transposed copy of W */
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);

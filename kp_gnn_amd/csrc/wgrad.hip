@@ -6,6 +6,8 @@
 // coalesced reads of 32 consecutive floats of a row - straight from global memory, no LDS, no transposes.
 // Wave w of a block owns output rows o in [32w, 32w+32) and ALL column tiles (TI accumulators of 16 VGPRs);
 // blocks split the N rows; partial dW strips go to a slab that is added in block order.
+#include <cstdlib>
+
 #include "kpgnn_common.h"
 
 namespace kpgnn {
@@ -115,97 +117,138 @@ namespace kpgnn {
 namespace {
 
 struct LinParams {
-    int64_t N; int O, I, pitch;
+    int64_t N; int O, I, pitch, ypitch, wt, dbg;
     const float* x; int64_t xs;
     const float* w; const float* bias;
     float* y; int64_t ys;
 };
 
-// KS = number of 2-wide k-steps held in registers (I <= 2*KS)
-template <int KS>
-__global__ void __launch_bounds__(512)
+constexpr int kLinMaxPF = 12;    // float4 registers per thread of the prefetched x tile (up to 96 x 128 floats)
+
+// y^T tile = W_strip (A operand, registers) x x_tile^T (B operand, LDS): wave w owns outputs [32w, 32w+32) for the
+// whole launch (KS k-steps of 2 = its strip of W in KS VGPRs); a block streams tiles of 32*M rows of x through LDS
+// (odd pitch: conflict-free transposed operand reads; the next tile travels in registers meanwhile); each wave runs M
+// independent v_mfma_f32_32x32x2_f32 chains (one per 32-row group) per k-step, and the result leaves through the same
+// LDS buffer as whole rows (coalesced 16-B stores).  M is chosen so that the launch is ONE round of tiles over two
+// blocks per CU (N = 47k: 96-row tiles, 495 blocks).  wt = 1 reads the weight transposed (w[k][o]): the same kernel
+// gives dx = dy W without a transposed copy.
+template <int KS, int M>
+__global__ void __launch_bounds__(256, 2)
 linear_fwd_kernel(const LinParams p) {
-    extern __shared__ __attribute__((aligned(16))) float xl[];      // [2][32][pitch]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) float xl[];      // [32*M][pitch]
+    constexpr int ROWS = 32 * M;
+    constexpr int PF = (M * 32 * 128 / 4 + 255) / 256 > kLinMaxPF ? kLinMaxPF : (M * 32 * 128 / 4 + 255) / 256;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 5, c = lane & 31;
-    const int nthreads = blockDim.x;
+    const int I = p.I, O = p.O, pitch = p.pitch;
     const int o = wave * 32 + c;
-    // A fragments: W[o][2*ks + kk]
+    // this wave's strip of the weight as MFMA A-fragments: a[ks] = W[o][2 ks + kk]
     float a[KS];
+    if (p.wt) {                                       // w is [I][O]: lanes run along o, coalesced as is
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int i = 2 * ks + kk;
-        a[ks] = (o < p.O && i < p.I) ? p.w[(int64_t)o * p.I + i] : 0.f;
-    }
-    const int64_t tiles = (p.N + 31) / 32;
-    const int tile_elems = 32 * p.I;
-    // staging map, tile independent: element e = threadIdx.x + q*nthreads of the [32, I] tile -> (row, column).
-    // The first NPRE elements per thread travel through registers (loaded before the MFMA loop of the current tile,
-    // written to the other LDS buffer after it); shapes with more elements per thread stage the rest directly.
-    constexpr int NPRE = 16;
-    int lo[NPRE], go[NPRE], rw[NPRE];
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-        const int e = threadIdx.x + q * nthreads;
-        const int r = e / p.I, i = e - r * p.I;
-        rw[q] = e < tile_elems ? r : 1 << 30;
-        lo[q] = r * p.pitch + i;
-        go[q] = (int)(r * p.xs + i);
-    }
-    float pre[NPRE];
-    auto load_regs = [&](int64_t tl) {
-        const int64_t r0 = tl * 32;
-        const float* base = p.x + r0 * p.xs;
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) pre[q] = (rw[q] < 32 && r0 + rw[q] < p.N) ? base[go[q]] : 0.f;
-    };
-    auto store_regs = [&](float* dst) {
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) if (rw[q] < 32) dst[lo[q]] = pre[q];
-    };
-    auto stage_rest = [&](int64_t tl, float* dst) {
-        const int64_t r0 = tl * 32;
-        for (int e = threadIdx.x + NPRE * nthreads; e < tile_elems; e += nthreads) {
-            const int r = e / p.I, i = e - r * p.I;
-            dst[r * p.pitch + i] = (r0 + r < p.N) ? p.x[(r0 + r) * p.xs + i] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) a[ks] = o < O ? p.w[(int64_t)(2 * ks + kk) * O + o] : 0.f;
+    } else {                                          // w is [O][I]: every lane streams ITS row 16 B at a time (the two
+#pragma unroll                                        // k-halves share the loads) instead of 2*KS strided dword loads
+        for (int j = 0; j < KS / 2; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < O) v = *reinterpret_cast<const float4*>(p.w + (int64_t)o * I + 4 * j);
+            a[2 * j] = kk ? v.y : v.x;
+            a[2 * j + 1] = kk ? v.w : v.z;
         }
+    }
+    const int64_t tiles = (p.N + ROWS - 1) / ROWS;
+    constexpr int IC = 2 * KS;                        // == I (host): compile-time divisor
+    int lo[PF];                                       // LDS offset of this thread's q-th float4 (tile independent)
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        const int e = 4 * (tid + q * 256);
+        lo[q] = e < ROWS * IC ? (e / IC) * pitch + (e % IC) : -1;
+    }
+    const int yp = p.ypitch;
+    int yo[PF];                                       // LDS offset of the q-th float4 of the y tile (one division, then steps)
+    {
+        const int step_r = 1024 / O, step_c = 1024 - step_r * O;
+        int r = (4 * tid) / O, cc = 4 * tid - r * O;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            yo[q] = r < ROWS ? r * yp + cc : 0;
+            r += step_r; cc += step_c;
+            if (cc >= O) { cc -= O; ++r; }
+        }
+    }
+    float4 pf[PF];
+    auto issue = [&](int64_t tl) {
+        const int64_t r0 = tl * ROWS;
+        const int64_t lim = (p.N - r0 < ROWS ? p.N - r0 : ROWS) * (int64_t)I;
+        const float* base = p.x + r0 * p.xs;          // xs == I (host): a tile is one contiguous run
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = 4 * (tid + q * 256);
+            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < lim) pf[q] = *reinterpret_cast<const float4*>(base + e);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+            if (lo[q] >= 0) *reinterpret_cast<float4*>(xl + lo[q]) = pf[q];
     };
     int64_t tile = blockIdx.x;
-    int buf = 0;
-    if (tile < tiles) { load_regs(tile); store_regs(xl); stage_rest(tile, xl); }
+    if (tile < tiles) { issue(tile); commit(); }
     __syncthreads();
     for (; tile < tiles; tile += gridDim.x) {
-        float* cur = xl + buf * 32 * p.pitch;
-        float* nxt = xl + (buf ^ 1) * 32 * p.pitch;
         const bool more = tile + gridDim.x < tiles;
-        if (more) load_regs(tile + gridDim.x);
-        f32x16 acc;
-        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const float* brow = cur + c * p.pitch + kk;
+        if (more) issue(tile + gridDim.x);
+        f32x16 acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+            for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
+        const float* b0 = xl + c * pitch + kk;
+        // I == 2 * KS exactly (host): plain LDS reads the scheduler can hoist ahead of the MFMAs (a per-lane predicate
+        // on the read made every MFMA wait for its own ds_read: 31 us instead of ~13)
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float b = (2 * ks + kk < p.I) ? brow[2 * ks] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b, acc, 0, 0, 0);
-        }
-        // C/D map: col = lane & 31 (row r of the tile), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
-        const int64_t r = tile * 32 + c;
-        if (r < p.N) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ob = wave * 32 + 8 * g + 4 * kk;
-                if (ob + 3 < p.O) {
-                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-                    if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + ob); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-                    *reinterpret_cast<float4*>(p.y + r * p.ys + ob) = v;
-                } else {
-                    for (int q = 0; q < 4; ++q)
-                        if (ob + q < p.O) p.y[r * p.ys + ob + q] = acc[4 * g + q] + (p.bias ? p.bias[ob + q] : 0.f);
-                }
+            for (int m = 0; m < M; ++m) {
+                const float xv = b0[m * 32 * pitch + 2 * ks];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xv, acc[m], 0, 0, 0);
             }
         }
-        if (more) { store_regs(nxt); stage_rest(tile + gridDim.x, nxt); }
+        __syncthreads();                               // every wave is done reading the x tile: it becomes the y tile
+        if (!(p.dbg & 2)) {
+        // C/D map: col = lane & 31 (tile row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ob = wave * 32 + 8 * g + 4 * kk;
+            if (ob < O) {                              // O % 4 == 0 (host): the 4 outputs of a group are in or out together
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + ob);
+#pragma unroll
+                for (int m = 0; m < M; ++m)            // y view: pitch = 4 (mod 8) floats -> 16-B LDS accesses, no conflicts
+                    *reinterpret_cast<float4*>(xl + (m * 32 + c) * yp + ob) =
+                        make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
+            }
+        }
         __syncthreads();
-        buf ^= 1;
+        {
+            const int64_t r0 = tile * ROWS;
+            const int rows = (int)(p.N - r0 < ROWS ? p.N - r0 : ROWS);
+            float* ybase = p.y + r0 * p.ys;            // ys == O (host): whole rows, contiguous
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = 4 * (tid + q * 256);
+                if (e < rows * O) *reinterpret_cast<float4*>(ybase + e) = *reinterpret_cast<const float4*>(xl + yo[q]);
+            }
+            for (int e = 4 * (tid + PF * 256); e < rows * O; e += 4 * 256) {
+                const int r = e / O, oo = e - r * O;
+                *reinterpret_cast<float4*>(ybase + e) = *reinterpret_cast<const float4*>(xl + r * yp + oo);
+            }
+        }
+        }
+        __syncthreads();                               // the y tile is out: the buffer takes the next x tile
+        if (more) commit();
+        __syncthreads();
     }
 }
 
@@ -215,31 +258,43 @@ linear_fwd_kernel(const LinParams p) {
 extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "linear_fwd: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_fwd: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
-    if (d->O > 256 || d->I > 256) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d, I=%d exceed 256", d->O, d->I);
-    KPGNN_REQUIRE(d->x && d->w && d->y && d->x_stride >= d->I && d->y_stride >= d->O, "linear_fwd: bad pointers/strides");
-    if ((d->y_stride % 4) != 0 || (((uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
-        return fail(KPGNN_ELIMIT, "linear_fwd: y / bias must be 16-B aligned with y_stride %% 4 == 0");
+    if (d->O > 128 || d->I > 128) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d, I=%d exceed 128", d->O, d->I);
+    KPGNN_REQUIRE(d->x && d->w && d->y, "linear_fwd: NULL pointer");
+    if ((d->O % 4) != 0 || (d->I % 4) != 0 || d->x_stride != d->I || d->y_stride != d->O ||
+        (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
+        return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
     LinParams p;
-    p.N = d->N; p.O = d->O; p.I = d->I; p.pitch = d->I | 1;   // odd pitch: conflict-free column reads
+    p.N = d->N; p.O = d->O; p.I = d->I; p.wt = d->w_transposed ? 1 : 0;
+    { const char* e = getenv("KPGNN_LIN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    // one pitch = 4 (mod 8) floats for the x and the y view of the buffer: 16-B aligned rows (the tile is committed and
+    // drained with b128 LDS accesses); the transposed operand reads then see a 2-way bank conflict, which hides behind
+    // the 64-cycle MFMAs
+    const int wmax = d->I > d->O ? d->I : d->O;
+    const int rowp = wmax + ((4 - wmax % 8) + 8) % 8;
+    p.pitch = rowp; p.ypitch = rowp;
     p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
-    const int waves = (d->O + 31) / 32;
-    const size_t lds = sizeof(float) * 2 * 32 * (size_t)p.pitch;
-    const int64_t tiles = (d->N + 31) / 32;
-    int64_t grid = (int64_t)device_facts().cu_count * 4;
-    if (grid > tiles) grid = tiles;
+    // rows per tile = 32 * m, m in 1..3, the smallest that makes the launch one round over two blocks per CU
+    const int64_t slots = (int64_t)device_facts().cu_count * 2;
+    int m = (int)((d->N + slots * 32 - 1) / (slots * 32));
+    m = m < 1 ? 1 : (m > 3 ? 3 : m);
+    { const char* e = getenv("KPGNN_LIN_M"); if (e && atoi(e) >= 1 && atoi(e) <= 3) m = atoi(e); }
+    const int rows = 32 * m;
+    const size_t lds = sizeof(float) * (size_t)rows * rowp;
+    const int64_t tiles = (d->N + rows - 1) / rows;
+    int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
     hipStream_t s = (hipStream_t)stream;
-    dim3 blk(waves * 64);
+    dim3 blk(256);
     const int ks = (d->I + 1) / 2;
-#define KP_LIN(KSV) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV>, lds)); \
-                         hipLaunchKernelGGL(linear_fwd_kernel<KSV>, dim3((unsigned)grid), blk, lds, s, p); } while (0)
-    if (ks <= 8) KP_LIN(8);
-    else if (ks <= 16) KP_LIN(16);
-    else if (ks <= 32) KP_LIN(32);
-    else if (ks <= 52) KP_LIN(52);
-    else if (ks <= 64) KP_LIN(64);
-    else if (ks <= 96) KP_LIN(96);
-    else KP_LIN(128);
+#define KP_LIN2(KSV, MV) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV, MV>, lds)); \
+                              hipLaunchKernelGGL((linear_fwd_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } while (0)
+#define KP_LIN(KSV) do { if (m == 1) KP_LIN2(KSV, 1); else if (m == 2) KP_LIN2(KSV, 2); else KP_LIN2(KSV, 3); } while (0)
+    if (ks == 16) KP_LIN(16);
+    else if (ks == 32) KP_LIN(32);
+    else if (ks == 52) KP_LIN(52);
+    else if (ks == 64) KP_LIN(64);
+    else return fail(KPGNN_ELIMIT, "linear_fwd: I=%d is not one of 32, 64, 104, 128 (the k-loop is fully unrolled)", d->I);
 #undef KP_LIN
+#undef KP_LIN2
     KPGNN_LAUNCH_CHECK("linear_fwd_kernel");
     return KPGNN_OK;
 }

@@ -78,24 +78,28 @@ class BatchNormAct(torch.autograd.Function):
 
 
 import os as _os
-# kpgnn_linear_fwd (fp32-MFMA streaming y = x W^T) is opt-in: measured 43 us per [47k,104]x[104,104] launch against
-# 24 us for the BLAS library's kernel (profiles/r01): the one-accumulator MFMA chain waits on its LDS operand
-# reads.  The weight-gradient kernel (34 us vs the library's 139 us) is always on.
-_USE_MFMA_LINEAR = _os.environ.get("KPGNN_MFMA_LINEAR", "0") == "1"
+# kpgnn_linear_fwd: y = x W^T + b and dx = dy W for tall-skinny x on the fp32 matrix cores.  Measured 21.8 us per
+# [47k,104] x [104,104] launch against 29 us for the BLAS library's kernel (profiles/r01): on by default for the shapes
+# it covers (I in {32, 64, 104, 128}, O % 4 == 0, O <= 128, contiguous operands, N >= 1024); KPGNN_MFMA_LINEAR=0 keeps
+# the library.  The weight-gradient kernel (34 us vs the library's 139 us) is always on.
+_USE_MFMA_LINEAR = _os.environ.get("KPGNN_MFMA_LINEAR", "1") == "1"
 
 
-def _mfma_linear(x, w, bias):
-    """y = x w^T + bias on kpgnn_linear_fwd (w: [O,I] contiguous).  Returns None when the shape is not covered."""
+def _mfma_linear(x, w, bias, transposed=False):
+    """y = x w^T + bias on kpgnn_linear_fwd (w: [O,I] contiguous), or y = x w with transposed=True (w: [I,O]).
+    Returns None when the shape is not covered."""
     if not _USE_MFMA_LINEAR:
         return None
     lib = _lib.load()
     N, I = x.shape
-    O = w.shape[0]
-    if O % 4 != 0 or O > 256 or I > 256:
+    O = w.shape[1] if transposed else w.shape[0]
+    if (O % 4 != 0 or I not in (32, 64, 104, 128) or O > 128 or N < 1024 or not x.is_contiguous()
+            or not w.is_contiguous() or x.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 16)):
         return None
     y = torch.empty((N, O), dtype=torch.float32, device=x.device)
     d = _lib.LinearDesc()
     d.N, d.O, d.I = N, O, I
+    d.w_transposed = 1 if transposed else 0
     d.x, d.x_stride, d.w, d.bias, d.y, d.y_stride = x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), y.stride(0)
     with torch.cuda.device(x.device):
         rc = lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(x))
@@ -128,8 +132,8 @@ class LinearWgrad(torch.autograd.Function):
         dev = dy.device
         dx = None
         if ctx.needs_input_grad[0]:
-            # dx = dy W  ==  dy (W^T)^T  (the transposed copy is only made when the opt-in MFMA forward kernel is on)
-            dx = _mfma_linear(dy, weight.t().contiguous(), None) if _USE_MFMA_LINEAR else None
+            # dx = dy W: the MFMA kernel reads W in its [O,I] layout (w_transposed), no copy
+            dx = _mfma_linear(dy if dy.is_contiguous() else dy.contiguous(), weight.contiguous(), None, transposed=True)
             if dx is None:
                 dx = dy @ weight
         # Weight gradients are leaves of the backward graph: nothing downstream waits for them until the optimiser.
