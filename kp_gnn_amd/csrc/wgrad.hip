@@ -14,7 +14,7 @@ namespace kpgnn {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kWgradBlocks = 256;
+constexpr int kWgradBlocks = 512;
 
 struct WgParams {
     int64_t N; int O, I;
