@@ -215,8 +215,26 @@ linear_fwd_kernel(const LinParams p) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xv, acc[m], 0, 0, 0);
             }
         }
+        if (p.dbg & 4) {                               // experiment: results straight from the accumulators (64 x 16-B segments per store)
+            const int64_t r0 = tile * ROWS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ob = wave * 32 + 8 * g + 4 * kk;
+                if (ob < O) {
+                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + ob);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int64_t r = r0 + m * 32 + c;
+                        if (r < p.N)
+                            *reinterpret_cast<float4*>(p.y + r * p.ys + ob) =
+                                make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
+                    }
+                }
+            }
+        }
         __syncthreads();                               // every wave is done reading the x tile: it becomes the y tile
-        if (!(p.dbg & 2)) {
+        if (!(p.dbg & 6)) {
         // C/D map: col = lane & 31 (tile row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -282,6 +300,7 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const size_t lds = sizeof(float) * (size_t)rows * rowp;
     const int64_t tiles = (d->N + rows - 1) / rows;
     int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
+    { const char* e = getenv("KPGNN_LIN_GRID"); if (e && atoi(e) >= 1 && atoi(e) < grid) grid = atoi(e); }
     hipStream_t s = (hipStream_t)stream;
     dim3 blk(256);
     const int ks = (d->I + 1) / 2;

@@ -15,11 +15,11 @@ def timeit(fn, n=50):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for mm in ("1", "2", "3"):
-    os.environ["KPGNN_LIN_M"] = mm
-    print("M =", mm, round(timeit(lambda: ops_dense._mfma_linear(x, w, b)), 1), "us", flush=True)
-os.environ.pop("KPGNN_LIN_M")
-for dbg in (0, 1, 2, 3):
+for mm, gg in (("1", "256"), ("1", "512"), ("2", "256"), ("1", "768"), ("2", "384"), ("3", "256")):
+    os.environ["KPGNN_LIN_M"] = mm; os.environ["KPGNN_LIN_GRID"] = gg
+    print("M =", mm, "grid", gg, round(timeit(lambda: ops_dense._mfma_linear(x, w, b)), 1), "us", flush=True)
+os.environ.pop("KPGNN_LIN_M"); os.environ.pop("KPGNN_LIN_GRID")
+for dbg in (0, 1, 2, 3, 4):
     os.environ["KPGNN_LIN_DEBUG"] = str(dbg)
     print(f"dbg={dbg}: mfma linear {timeit(lambda: ops_dense._mfma_linear(x, w, b)):.1f} us", flush=True)
 os.environ["KPGNN_LIN_DEBUG"] = "0"
