@@ -34,6 +34,7 @@ struct TgmParams {
     const float* theta;
     const float* gh;
     float* slab;              // [gridDim.x * KQ][R][D]
+    int dbg;                  // KPGNN_TG_DEBUG ablation bits (experiments only): 1 no MFMA phase, 2 no count matrix, 4 no tile copy
 };
 
 template <int MAXIT, int MTMAX>
@@ -122,7 +123,8 @@ table_grad_mfma_kernel(const TgmParams p) {
         const int beg = nbeg, end = nend, myu = nu;
         const uint32_t myw = nw;
         __syncthreads();                             // previous tile: MFMA reads and cell resets are done
-        if (p.vec4) {
+        if (p.dbg & 4) {
+        } else if (p.vec4) {
 #pragma unroll
             for (int q = 0; q < kTgmPF; ++q) {
                 const int i = 4 * (tid + q * kTgmThreads);
@@ -137,7 +139,7 @@ table_grad_mfma_kernel(const TgmParams p) {
             for (int i = tid; i < tile_floats; i += kTgmThreads) tile[i] = (base + i < total) ? p.g[base + i] : 0.f;
         }
         // count matrix of this tile
-        {
+        if (!(p.dbg & 2)) {
             const int c = cell_of(myw);
             if (c >= 0) atomicAdd(&cnt[c], 1);
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
@@ -159,7 +161,7 @@ table_grad_mfma_kernel(const TgmParams p) {
             if (nx < num_tiles) { issue_tile(nx); issue_meta(nx); }
         }
         // C x g_tile
-        if (wave < nitems) {
+        if (wave < nitems && !(p.dbg & 1)) {
             int n_idx = n_start, k_idx = k_start;
             for (int q = q0; q < q1; ++q) {
                 const int row = 4 * q + lq;
@@ -195,7 +197,7 @@ table_grad_mfma_kernel(const TgmParams p) {
         }
         __syncthreads();
         // reset the touched cells (cheaper than clearing Rp x CP words per tile)
-        {
+        if (!(p.dbg & 2)) {
             const int c = cell_of(myw);
             if (c >= 0) cnt[c] = 0;
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
@@ -635,6 +637,7 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
     p.slab = (float*)d->workspace;
+    { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
 #define KP_TGM(IT, MTV) do { \
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_mfma_kernel<IT, MTV>, pl.lds)); \
         hipLaunchKernelGGL((table_grad_mfma_kernel<IT, MTV>), dim3(pl.grid), dim3(kTgmThreads), pl.lds, s, p); } while (0)
