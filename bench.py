@@ -75,13 +75,23 @@ def train_step(model, batch, opt, flat_grad, world, graph=None):
     """One optimisation step.  With `graph` (a captured hipGraph of fwd+bwd on this batch's static tensors) the
     ~1,500 launches of forward+backward replay as one graph launch; the gradient all-reduce and the fused Adam
     step stay eager (a collective inside a captured graph is the one thing that cannot be rehearsed on 1 GPU)."""
+    trace = os.environ.get("KPGNN_BENCH_TRACE") == "1"
+    if trace:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
     if graph is not None:
         graph[0].replay()
         loss = graph[1]
     else:
         loss = fwd_bwd(model, batch, flat_grad)
+    if trace:
+        torch.cuda.synchronize(); t1 = time.perf_counter()
     dp.allreduce_mean(flat_grad, world)
+    if trace:
+        torch.cuda.synchronize(); t2 = time.perf_counter()
     opt.step()
+    if trace:
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        log(f"step phases: fwd+bwd {1e3*(t1-t0):.1f} ms, all-reduce {1e3*(t2-t1):.1f} ms, optimizer {1e3*(t3-t2):.1f} ms")
     return loss
 
 

@@ -55,6 +55,10 @@ def allreduce_mean(flat, world):
     gradients is the gradient of the global mean loss the reference computes on GPU 0 (train_ZINC.py:36,42)."""
     if world <= 1:
         return
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal path only (gloo stages device tensors through the host): without this the collective's internal
+        # stream waits fight the still-running graph replay of the ranks sharing one GPU (seconds per step)
+        torch.cuda.synchronize(flat.device)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world)
 
