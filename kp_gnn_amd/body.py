@@ -337,10 +337,13 @@ class GNN(_KHopBody):
         for l in range(self.num_layer):
             if self.virtual_node:
                 h_list[l] = h_list[l] + vn[batch]
-            h = self.norms[l](self.gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph))
+            # norm (+ residual) in one pass whenever no dropout mask sits between them (as in GNNPlus below)
+            fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
+            h = self.norms[l](self.gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph),
+                              residual=h_list[l] if fuse_res else None)
             if l != self.num_layer - 1:
                 h = self.dropout(h)
-            if self.residual:
+            if self.residual and not fuse_res:
                 h = h + h_list[l]
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:
@@ -438,10 +441,12 @@ class GNNPrime(_KHopBody):
                 h = self.khop_gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph)
             else:
                 h = self.gins[l - self.num_l1_layer](h_list[l], edge_index, edge_attr[:, :1])
-            h = self.norms[l](h)
-            if l < self.num_l1_layer or l != self.num_layer - 1:  # (:659 drops out after every K-hop layer)
+            drops = l < self.num_l1_layer or l != self.num_layer - 1   # (:659 drops out after every K-hop layer)
+            fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or not drops)
+            h = self.norms[l](h, residual=h_list[l] if fuse_res else None)
+            if drops:
                 h = self.dropout(h)
-            if self.residual:
+            if self.residual and not fuse_res:
                 h = h + h_list[l]
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:
