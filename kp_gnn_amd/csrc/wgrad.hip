@@ -270,13 +270,94 @@ linear_fwd_kernel(const LinParams p) {
     }
 }
 
+// Wide outputs (O > 128, e.g. the input gradient of the jumping-knowledge projection: [N,104] x [104,936]): the x tile
+// stays resident in LDS while the block walks the outputs 128 at a time - per chunk every wave reloads its strip of the
+// weight (L2-resident) and runs its MFMA chains; results go straight from the accumulators to y (64 x 16-B segments per
+// store: measured as fast as staging through LDS), so no barrier separates the chunks.
+template <int KS, int M>
+__global__ void __launch_bounds__(256, 2)
+linear_wide_kernel(const LinParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xl[];      // [32*M][pitch]
+    constexpr int ROWS = 32 * M;
+    constexpr int IC = 2 * KS;                        // == I (host)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kk = lane >> 5, c = lane & 31;
+    const int O = p.O, pitch = p.pitch;
+    const int64_t tiles = (p.N + ROWS - 1) / ROWS;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();                               // previous tile fully consumed
+        {   // x tile -> LDS (no register double-buffer: the eight output chunks dwarf this load)
+            const int64_t r0 = tile * ROWS;
+            const int lim = (int)(p.N - r0 < ROWS ? p.N - r0 : ROWS) * IC;
+            const float* base = p.x + r0 * p.xs;
+            for (int e = 4 * tid; e < ROWS * IC; e += 4 * 256) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < lim) v = *reinterpret_cast<const float4*>(base + e);
+                *reinterpret_cast<float4*>(xl + (e / IC) * pitch + (e % IC)) = v;
+            }
+        }
+        __syncthreads();
+        const int64_t r0 = tile * ROWS;
+        const float* b0 = xl + c * pitch + kk;
+#pragma unroll 1
+        for (int chunk = 0; chunk < O; chunk += 128) {
+            // the operand reads below do not depend on the chunk: without this the compiler hoists all of them out of
+            // the loop and spills ~500 registers
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const float* bz = b0 + z;
+            const int o = chunk + wave * 32 + c;
+            float a[KS];
+            if (p.wt) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a[ks] = o < O ? p.w[(int64_t)(2 * ks + kk) * O + o] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < KS / 2; ++j) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o < O) v = *reinterpret_cast<const float4*>(p.w + (int64_t)o * IC + 4 * j);
+                    a[2 * j] = kk ? v.y : v.x;
+                    a[2 * j + 1] = kk ? v.w : v.z;
+                }
+            }
+            f32x16 acc[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+                for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float xv = bz[m * 32 * pitch + 2 * ks];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xv, acc[m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ob = chunk + wave * 32 + 8 * g + 4 * kk;
+                if (ob < O) {
+                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + ob);
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int64_t r = r0 + m * 32 + c;
+                        if (r < p.N)
+                            *reinterpret_cast<float4*>(p.y + r * p.ys + ob) =
+                                make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace kpgnn
 
 extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "linear_fwd: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_fwd: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
-    if (d->O > 128 || d->I > 128) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d, I=%d exceed 128", d->O, d->I);
+    if (d->O > 4096 || d->I > 128) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d exceeds 4096 or I=%d exceeds 128", d->O, d->I);
     KPGNN_REQUIRE(d->x && d->w && d->y, "linear_fwd: NULL pointer");
     if ((d->O % 4) != 0 || (d->I % 4) != 0 || d->x_stride != d->I || d->y_stride != d->O ||
         (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
@@ -287,7 +368,8 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     // one pitch = 4 (mod 8) floats for the x and the y view of the buffer: 16-B aligned rows (the tile is committed and
     // drained with b128 LDS accesses); the transposed operand reads then see a 2-way bank conflict, which hides behind
     // the 64-cycle MFMAs
-    const int wmax = d->I > d->O ? d->I : d->O;
+    const bool wide = d->O > 128;
+    const int wmax = (wide || d->I > d->O) ? d->I : d->O;
     const int rowp = wmax + ((4 - wmax % 8) + 8) % 8;
     p.pitch = rowp; p.ypitch = rowp;
     p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
@@ -304,8 +386,12 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     hipStream_t s = (hipStream_t)stream;
     dim3 blk(256);
     const int ks = (d->I + 1) / 2;
-#define KP_LIN2(KSV, MV) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV, MV>, lds)); \
-                              hipLaunchKernelGGL((linear_fwd_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } while (0)
+#define KP_LIN2(KSV, MV) do { if (wide) { \
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_wide_kernel<KSV, MV>, lds)); \
+        hipLaunchKernelGGL((linear_wide_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); \
+    } else { \
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV, MV>, lds)); \
+        hipLaunchKernelGGL((linear_fwd_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } } while (0)
 #define KP_LIN(KSV) do { if (m == 1) KP_LIN2(KSV, 1); else if (m == 2) KP_LIN2(KSV, 2); else KP_LIN2(KSV, 3); } while (0)
     if (ks == 16) KP_LIN(16);
     else if (ks == 32) KP_LIN(32);

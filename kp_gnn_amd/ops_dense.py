@@ -80,7 +80,8 @@ class BatchNormAct(torch.autograd.Function):
 import os as _os
 # kpgnn_linear_fwd: y = x W^T + b and dx = dy W for tall-skinny x on the fp32 matrix cores.  Measured 21.8 us per
 # [47k,104] x [104,104] launch against 29 us for the BLAS library's kernel (profiles/r01): on by default for the shapes
-# it covers (I in {32, 64, 104, 128}, O % 4 == 0, O <= 128, contiguous operands, N >= 1024); KPGNN_MFMA_LINEAR=0 keeps
+# it covers (I in {32, 64, 104, 128}, O % 4 == 0, contiguous operands, N >= 1024; O > 128 walks the outputs in
+# chunks of 128 over an LDS-resident x tile: 118 us vs the library's 146 us for [47k,104] x [104,936]); KPGNN_MFMA_LINEAR=0 keeps
 # the library.  The weight-gradient kernel (34 us vs the library's 139 us) is always on.
 _USE_MFMA_LINEAR = _os.environ.get("KPGNN_MFMA_LINEAR", "1") == "1"
 
@@ -93,7 +94,7 @@ def _mfma_linear(x, w, bias, transposed=False):
     lib = _lib.load()
     N, I = x.shape
     O = w.shape[1] if transposed else w.shape[0]
-    if (O % 4 != 0 or I not in (32, 64, 104, 128) or O > 128 or N < 1024 or not x.is_contiguous()
+    if (O % 4 != 0 or I not in (32, 64, 104, 128) or O > 4096 or N < 1024 or not x.is_contiguous()
             or not w.is_contiguous() or x.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 16)):
         return None
     y = torch.empty((N, O), dtype=torch.float32, device=x.device)

@@ -623,7 +623,8 @@ def test_per_hop_slot_inputs_equal_stacked_input():
             _close(res[1][2][k], res[0][2][k], "grad " + k, atol=3e-5)
 
 
-@pytest.mark.parametrize("N,O,I", [(4099, 104, 104), (1500, 64, 104), (1057, 32, 32), (2048, 128, 128), (1024, 104, 64), (47450, 104, 104)])
+@pytest.mark.parametrize("N,O,I", [(4099, 104, 104), (1500, 64, 104), (1057, 32, 32), (2048, 128, 128), (1024, 104, 64), (47450, 104, 104),
+                                   (3001, 936, 104), (1100, 132, 32)])
 def test_mfma_linear_forward_kernel(N, O, I):
     """kpgnn_linear_fwd: y = x W^T + b and (w_transposed) dx = dy W on the fp32 matrix cores vs torch; asymmetric data,
     partial last tiles, output strips that are not a multiple of 32."""
@@ -632,17 +633,20 @@ def test_mfma_linear_forward_kernel(N, O, I):
     g = torch.Generator().manual_seed(N + O + I)
     x = torch.randn(N, I, generator=g) * (1 + 0.01 * torch.arange(I))
     w, b = torch.randn(O, I, generator=g) * 0.1, torch.randn(O, generator=g)
-    dy = torch.randn(N, O, generator=g) * (1 + 0.02 * torch.arange(O))
+    if O > 128:      # wide outputs (the input gradient of the jumping-knowledge projection): dy [N, I] times a [I, O] weight
+        dy, wd = x, torch.randn(I, O, generator=g) * 0.1
+    else:
+        dy, wd = torch.randn(N, O, generator=g) * (1 + 0.02 * torch.arange(O)), w
     saved = ops_dense._USE_MFMA_LINEAR
     ops_dense._USE_MFMA_LINEAR = True
     try:
         y = ops_dense._mfma_linear(x.to(dev), w.to(dev), b.to(dev))
-        dx = ops_dense._mfma_linear(dy.to(dev), w.to(dev), None, transposed=True)
+        dx = ops_dense._mfma_linear(dy.to(dev), wd.to(dev), None, transposed=True)
     finally:
         ops_dense._USE_MFMA_LINEAR = saved
     assert y is not None and dx is not None
     _close(y, torch.nn.functional.linear(x, w, b), "y", rtol=2e-4, atol=2e-5)
-    _close(dx, dy @ w, "dx", rtol=2e-4, atol=2e-5)
+    _close(dx, dy @ wd, "dx", rtol=2e-4, atol=2e-5)
 
 
 def test_fused_backward_prepass_equals_two_kernel_path():
