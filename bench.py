@@ -329,6 +329,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, sd, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()        # rank 0 ran the per-launch timing leg alone: tear the communicator down together
         torch.distributed.destroy_process_group()
 
 
