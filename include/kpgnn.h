@@ -67,10 +67,15 @@ size_t kpgnn_csr_workspace_bytes(int64_t E, int64_t A, int64_t N, int32_t K);
  *   rowptr_src int32[N*K+1], col_src int32[A] (= dest node),   code_src uint16[A]   -- keyed by (src,hop)
  * Entries of one segment keep the order of the input edge list (stable), which is the reference's CPU
  * summation order (index_add_ over edges in order).
- * Optional third ordering for kpgnn_table_grad (tile_ptr == NULL skips it): the active pairs sorted by
- * (destination tile, table, code), tile = dst / nodes_per_tile (1..8):
- *   tile_ptr int32[ceil(N/nodes_per_tile)+1], tile_pack uint32[A] = table<<31 | code<<15 | node_in_tile<<12 | hop
- *   (table 0 = hop 0 -> hop1_edge_emb, table 1 = hops >= 1 -> hopk_edge_emb; codes < 2^16, hops < 2^12). */
+ * Optional third ordering for kpgnn_table_grad (tile_ptr == NULL skips it; needs K <= 62): per tile of
+ * nodes_per_tile (1..8) destination nodes, one entry per DISTINCT (node, hop, code) with its multiplicity (pairs of
+ * one segment that carry the same code add the same gradient row to the same table row), sorted by
+ * (tile, table, code, hop, node_in_tile):
+ *   tile_ptr  int32[ceil(N/nodes_per_tile)+1]   (tile_ptr[last] = number of entries <= A)
+ *   tile_pack uint32[A] (at most A entries are written) =
+ *             table<<31 | code<<15 | node_in_tile<<12 | (multiplicity-1)<<6 | hop
+ *   (table 0 = hop 0 -> hop1_edge_emb, table 1 = hops >= 1 -> hopk_edge_emb; codes < 2^16; multiplicity 1..64, longer
+ *   runs are split). */
 int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t* edge_attr, int64_t attr_stride,
                     int64_t E, int32_t K, int64_t N, int64_t A,
                     int32_t* rowptr_dst, int32_t* col_dst, uint16_t* code_dst,

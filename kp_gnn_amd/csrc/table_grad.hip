@@ -118,9 +118,57 @@ table_grad_kernel(const TgParams p) {
                 pref[q] = *reinterpret_cast<const float4*>(p.g + i);
         }
     }
+    // Per-tile metadata travels two tiles ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the
+    // window that arrived an iteration ago, the first 64 entries / dictionary ids / gh values of tile i+1.  Read at the
+    // point of use they were two DEPENDENT global round trips per tile (tile_ptr -> tile_pack) in front of a walk that
+    // itself takes well under a microsecond: 56 of the kernel's 92 us at k = 8.
+    struct TileMeta { int beg, end; uint32_t nxt; int uid; float gh[2]; };
+    static_assert(kGroups * 2 >= 8, "two gh values per thread cover a tile of up to 8 nodes");
+    // window of tile t2: lane 0 fetches its begin, lane 1 its end (kept as a per-lane value on purpose: a wave-uniform
+    // load is waited for where it is issued, to move it to scalar registers)
+    auto load_range = [&](int64_t t2) -> int {
+        int v = 0;
+        if (p.tptr && t2 < num_tiles && lane < 2) v = p.tptr[t2 + lane];
+        return v;
+    };
+    auto load_meta = [&](int64_t t2, int rb, int re, TileMeta& m) {
+        // this group's contiguous chunk of the sorted entry list (multiple of 8 entries except the tail)
+        const int per = ((re - rb + kGroups - 1) / kGroups + 7) & ~7;
+        m.beg = min(re, rb + grp * per);
+        m.end = min(re, m.beg + per);
+        m.nxt = (m.beg + lane < m.end) ? p.tpack[m.beg + lane] : 0xFFFFFFFFu;   // hop 63 == skip
+        m.uid = -1;                                  // lane l: dictionary row of tile row l (NT*K <= 64)
+        if (p.U > 0 && lane < p.NT * p.K && t2 < num_tiles) {
+            const int n = lane / p.K;
+            const int64_t node = t2 * p.NT + n;
+            if (node < p.N) m.uid = p.uid[node * p.uid_stride + (lane - n * p.K)];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                // gh rows of the tile's nodes, column t
+            const int n = grp + q * kGroups;
+            const int64_t node = t2 * p.NT + n;
+            m.gh[q] = (p.dict_src == 1 && n < p.NT && t2 < num_tiles && node < p.N && col_ok) ? p.gh[node * D + d] : 0.f;
+        }
+    };
+    TileMeta cm;
+    int rng1;
+    {
+        const int rng0 = load_range(blockIdx.x);
+        load_meta(blockIdx.x, __builtin_amdgcn_readlane(rng0, 0), __builtin_amdgcn_readlane(rng0, 1), cm);
+        rng1 = load_range((int64_t)blockIdx.x + gridDim.x);
+    }
     for (int64_t tl = blockIdx.x; tl < num_tiles; tl += gridDim.x) {
-        int beg = 0, end = 0;
-        if (p.tptr) { beg = p.tptr[tl]; end = p.tptr[tl + 1]; }
+        // Consume this tile's metadata NOW (requested an iteration ago): the wait must sit in front of the loads issued
+        // below for the next tile - a wait placed inside the walk is a vmcnt(0) that also waits for the g rows just
+        // requested for the next tile, i.e. one exposed HBM round trip per tile (56 of 92 us at k = 8).
+        uint32_t mine = cm.nxt;
+        int myuid = cm.uid;                           // lane l: dictionary row of tile row l
+        float gh0 = cm.gh[0], gh1 = cm.gh[1];
+        asm volatile("" : "+v"(mine), "+v"(myuid), "+v"(gh0), "+v"(gh1));
+        TileMeta nm;                                  // next tile (its window arrived with the loads above) and the one after
+        load_meta(tl + gridDim.x, __builtin_amdgcn_readlane(rng1, 0), __builtin_amdgcn_readlane(rng1, 1), nm);
+        rng1 = load_range(tl + 2 * (int64_t)gridDim.x);
+        int beg = cm.beg, end = cm.end;
         const int64_t base = tl * tile_floats;
         const int nfl = (int)min((int64_t)tile_floats, total - base);
         __syncthreads();                             // previous tile fully walked
@@ -182,24 +230,9 @@ table_grad_kernel(const TgParams p) {
         } else {
             for (int i = threadIdx.x; i < nfl; i += kThreadsTG) tile[i] = p.g[base + i];
         }
-        {   // this group's contiguous chunk of the sorted pair list (multiple of 8 entries except the tail)
-            const int len = end - beg;
-            const int per = ((len + kGroups - 1) / kGroups + 7) & ~7;
-            beg = min(end, beg + grp * per);
-            end = min(end, beg + per);
-        }
-        uint32_t nxt = (beg + lane < end) ? p.tpack[beg + lane] : 0xFFFFFFFFu;   // hop 0xFFF == skip
-        int myuid = -1;                              // lane l: dictionary row of tile row l (NT*K <= 64), in flight during the walk
-        if (p.U > 0 && lane < p.NT * p.K) {
-            const int n = lane / p.K;
-            const int64_t node = tl * p.NT + n;
-            if (node < p.N) myuid = p.uid[node * p.uid_stride + (lane - n * p.K)];
-        }
-        if (p.dict_src == 1) {                       // gh rows of the tile's nodes, column t
-            for (int n = grp; n < p.NT; n += kGroups) {
-                const int64_t node = tl * p.NT + n;
-                ghs[n * kCols + t] = (node < p.N && col_ok) ? p.gh[node * D + d] : 0.f;
-            }
+        if (p.dict_src == 1) {
+            if (grp < p.NT) ghs[grp * kCols + t] = gh0;
+            if (grp + kGroups < p.NT) ghs[(grp + kGroups) * kCols + t] = gh1;
         }
         __syncthreads();
         // ---- walk the (table,code)-sorted pair list of this tile.  Each wave fetches 64 entries with ONE
@@ -207,23 +240,27 @@ table_grad_kernel(const TgParams p) {
         //      scalar-cache misses); the LDS tile reads of 8 entries are issued back to back before the
         //      (sequential, register-only) run accumulation.  The next chunk is fetched while this one is walked.
         if (p.dbg & 1) end = beg;
-        for (int b0 = beg; b0 < end; b0 += 64) {
-            const uint32_t mine = nxt;
-            if (b0 + 64 < end) nxt = (b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu;
-            const int cnt = min(64, end - b0);
-            // every lane decodes ITS entry once (VALU, 64 entries per instruction); the per-entry scalar work is
-            // then two v_readlane, one compare and the add
-            const int vhop = mine & 0xFFF;
+        // every lane decodes ITS entry once (VALU, 64 entries per instruction); the per-entry scalar work is then three
+        // v_readlane, one compare and the fma
+        int vmul, voff, vrow;
+        auto decode = [&](uint32_t w) {
+            const int vhop = w & 0x3F;
             const bool vok = vhop < p.K;
-            const int voff = vok ? ((int)((mine >> 12) & 7) * p.K + vhop) * D : 0;
-            const int vcc = (int)(mine >> 15);                             // table<<16 | code
-            const int vrow = vok ? ((vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc) : -1;
+            vmul = __float_as_int((float)(((w >> 6) & 0x3F) + 1));        // multiplicity of the merged entry
+            voff = vok ? ((int)((w >> 12) & 7) * p.K + vhop) * D : 0;
+            const int vcc = (int)(w >> 15);                                // table<<16 | code
+            vrow = vok ? ((vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc) : -1;
+        };
+        decode(mine);
+        for (int b0 = beg; b0 < end; b0 += 64) {
+            const int cnt = min(64, end - b0);
             for (int e0 = 0; e0 < cnt; e0 += 8) {
-                int off[8], row[8]; float val[8];
+                int off[8], row[8]; float val[8], mul[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     off[u] = __builtin_amdgcn_readlane(voff, e0 + u);
                     row[u] = __builtin_amdgcn_readlane(vrow, e0 + u);
+                    mul[u] = __int_as_float(__builtin_amdgcn_readlane(vmul, e0 + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) val[u] = tile[off[u] + dc];
@@ -235,10 +272,12 @@ table_grad_kernel(const TgParams p) {
                             cur = row[u];
                             run = 0.f;
                         }
-                        run += val[u];
+                        run = fmaf(mul[u], val[u], run);
                     }
                 }
             }
+            if (b0 + 64 < end)                       // (rare: > 64 entries in a group's chunk; fetched and decoded here so
+                decode((b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu);   //  that the loop carries no pending load)
         }
         // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register;
         //      theta / gh sit in registers, the (wave-uniform) uids of a node are fetched together
@@ -260,6 +299,7 @@ table_grad_kernel(const TgParams p) {
                 }
             }
         }
+        cm = nm;
     }
     if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
     if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);

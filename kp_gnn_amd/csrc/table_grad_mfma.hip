@@ -24,6 +24,8 @@ constexpr int kTgmThreads = 256;
 constexpr int kTgmWaves = 4;
 constexpr int kTgmPF = 8;     // float4 registers per thread of the prefetched g tile (covers 8192 floats)
 
+__device__ __forceinline__ int mult_of(uint32_t w) { return (int)((w >> 6) & 0x3Fu) + 1; }   // merged-entry multiplicity
+
 struct TgmParams {
     int N, K, D, NT, n0, U, dict_src;
     int RE, REp, Rp, R, MT, MTE, rows, QS, CP, NTILES, KQ, vec4;
@@ -109,7 +111,7 @@ table_grad_mfma_kernel(const TgmParams p) {
     if ((int64_t)blockIdx.x < num_tiles) { issue_tile(blockIdx.x); issue_meta(blockIdx.x); }
 
     auto cell_of = [&](uint32_t w) -> int {          // LDS index of the count cell of a packed pair, -1 = skip
-        const int hop = (int)(w & 0xFFF);
+        const int hop = (int)(w & 0x3F);
         if (hop >= K) return -1;
         const int nit = (int)((w >> 12) & 7);
         const int cc = (int)(w >> 15);               // table<<16 | code
@@ -141,10 +143,11 @@ table_grad_mfma_kernel(const TgmParams p) {
         // count matrix of this tile
         if (!(p.dbg & 2)) {
             const int c = cell_of(myw);
-            if (c >= 0) atomicAdd(&cnt[c], 1);
+            if (c >= 0) atomicAdd(&cnt[c], mult_of(myw));
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
-                const int c2 = cell_of(p.tpack[e]);
-                if (c2 >= 0) atomicAdd(&cnt[c2], 1);
+                const uint32_t w2 = p.tpack[e];
+                const int c2 = cell_of(w2);
+                if (c2 >= 0) atomicAdd(&cnt[c2], mult_of(w2));
             }
             if ((unsigned)myu < (unsigned)p.U) cnt[(p.REp + myu) * CP + tid] = 1;   // one dictionary row per tile row
         }
@@ -304,15 +307,10 @@ table_grad_bf16_kernel(const TgbParams p) {
 
     const int64_t num_tiles = ((int64_t)p.N + p.NT - 1) / p.NT;
     const int64_t total = (int64_t)p.N * K * D;
-    // a block owns a CONTIGUOUS range of tiles; the row pointers of its range sit in LDS, so the pair list of the
-    // next tile can be requested without a dependent tptr -> tpack round trip
+    // a block owns a CONTIGUOUS range of tiles
     const int64_t per = (num_tiles + gridDim.x - 1) / gridDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * per;
     const int64_t t1 = t0 + per < num_tiles ? t0 + per : num_tiles;
-    int* tpl = reinterpret_cast<int*>(ghs + p.NT * D);        // [per + 1]
-    if (p.tptr)
-        for (int i = tid; i <= (int)(t1 - t0) && t0 < t1; i += kTgmThreads) tpl[i] = p.tptr[t0 + i];
-    __syncthreads();
     float4 pf[kTgmPF];
     auto issue_tile = [&](int64_t tl) {
         if (!p.vec4) return;
@@ -329,7 +327,7 @@ table_grad_bf16_kernel(const TgbParams p) {
     auto issue_meta = [&](int64_t tl) {
         nbeg = nend = 0; nw = 0xFFFFFFFFu; nu = -1;
         if (p.tptr) {
-            nbeg = tpl[tl - t0]; nend = tpl[tl - t0 + 1];
+            nbeg = p.tptr[tl]; nend = p.tptr[tl + 1];
             if (nbeg + tid < nend) nw = p.tpack[nbeg + tid];
         }
         if (p.U > 0 && tid < rows) {
@@ -340,7 +338,7 @@ table_grad_bf16_kernel(const TgbParams p) {
     };
     if (t0 < t1) { issue_tile(t0); issue_meta(t0); }
     auto cell_of = [&](uint32_t w) -> int {
-        const int hop = (int)(w & 0xFFF);
+        const int hop = (int)(w & 0x3F);
         if (hop >= K) return -1;
         const int nit = (int)((w >> 12) & 7);
         const int cc = (int)(w >> 15);
@@ -371,10 +369,11 @@ table_grad_bf16_kernel(const TgbParams p) {
         }
         if (!(p.dbg & 2)) {
             const int c = cell_of(myw);
-            if (c >= 0) atomicAdd(&cnt[c], 1.0f);
+            if (c >= 0) atomicAdd(&cnt[c], (float)mult_of(myw));
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
-                const int c2 = cell_of(p.tpack[e]);
-                if (c2 >= 0) atomicAdd(&cnt[c2], 1.0f);
+                const uint32_t w2 = p.tpack[e];
+                const int c2 = cell_of(w2);
+                if (c2 >= 0) atomicAdd(&cnt[c2], (float)mult_of(w2));
             }
             if ((unsigned)myu < (unsigned)p.U) cnt[(p.REp + myu) * CP + tid] = 1.0f;
         }

@@ -345,28 +345,43 @@ def test_table_gather_sum_vs_torch(D, R_sizes):
     _close(bd.grad, br.grad, "gbias", atol=3e-5)
 
 
-def test_tile_sorted_pair_list_is_a_permutation_of_the_csr():
-    """The third CSR ordering (tile, table, code): same multiset of (dst, hop, code) as the by-destination CSR."""
+@pytest.mark.parametrize("N,E,K,ncode", [(203, 3000, 6, 9), (64, 20000, 3, 3), (10, 0, 4, 3)])
+def test_tile_entry_list_merges_the_csr_pairs(N, E, K, ncode):
+    """The third CSR ordering: one entry per distinct (node, hop, code) with its multiplicity, sorted by
+    (tile, table, code, hop, node).  Expanding the multiplicities gives back the multiset of (dst, hop, code) of the
+    by-destination CSR; runs longer than 64 are split (second case: ~94 pairs per (node, hop))."""
     from kp_gnn_amd.khop_csr import KHopCSR
-    N, E, K = 203, 3000, 6
-    ei, ea = _random_khop(N, E, K, seed=21)
+    ei, ea = _random_khop(N, max(E, 1), K, seed=21, n0=ncode, nk=ncode)
+    if E == 0:
+        ea = torch.zeros_like(ea)
     csr = KHopCSR.build(ei.to(_dev()), ea.to(_dev()), N)
-    pack = csr.tile_pack.cpu().numpy().astype(np.uint32)[:csr.A]
-    tptr = csr.tile_ptr.cpu().numpy()
+    tptr = csr.tile_ptr.cpu().numpy().astype(np.int64)
     NT = csr.nodes_per_tile
-    assert tptr[0] == 0 and tptr[-1] == csr.A and (np.diff(tptr) >= 0).all()
-    tile_of = np.repeat(np.arange(len(tptr) - 1), np.diff(tptr))
-    hop = pack & 0xFFF
-    node = tile_of * NT + ((pack >> 12) & 7)
-    code = (pack >> 15) & 0xFFFF
-    table = pack >> 31
-    assert ((hop == 0) == (table == 0)).all()
-    got = sorted(zip(node.tolist(), hop.tolist(), code.tolist()))
+    ntiles = (N + NT - 1) // NT
+    assert tptr.shape[0] == ntiles + 1 and tptr[0] == 0 and (np.diff(tptr) >= 0).all()
+    M = int(tptr[-1])
+    assert M <= csr.A
+    pack = csr.tile_pack.cpu().numpy().astype(np.uint32)[:M]
+    tile_of = np.repeat(np.arange(ntiles), np.diff(tptr))
+    hop = (pack & 0x3F).astype(np.int64)
+    mult = ((pack >> 6) & 0x3F).astype(np.int64) + 1
+    nit = ((pack >> 12) & 7).astype(np.int64)
+    code = ((pack >> 15) & 0xFFFF).astype(np.int64)
+    table = (pack >> 31).astype(np.int64)
+    assert ((hop == 0) == (table == 0)).all() and (hop < K).all()
+    node = tile_of * NT + nit
+    assert int(mult.sum()) == csr.A
+    got = sorted(np.repeat(np.stack([node, hop, code], 1), mult, axis=0).tolist())
     e, k = np.nonzero(ea.numpy())
     want = sorted(zip(ei.numpy()[1][e].tolist(), k.tolist(), ea.numpy()[e, k].tolist()))
-    assert got == want
-    key = (tile_of.astype(np.int64) << 17) | (table.astype(np.int64) << 16) | code
+    assert got == [list(w) for w in want]
+    key = (tile_of << 26) | (table << 25) | (code << 9) | (hop << 3) | nit
     assert (np.diff(key) >= 0).all()
+    # merged: equal neighbours only where a run was cut at a multiple of 64 sorted positions
+    dup = np.nonzero(np.diff(key) == 0)[0]
+    assert len(dup) <= csr.A // 64 + 1
+    if len(dup) == 0 and M > 0:
+        assert len(set(key.tolist())) == M
 
 
 @pytest.mark.parametrize("kind,combine", [("KPGIN", "geometric"), ("KPGINPlus", "geometric"), ("KPGINPlus", "attention"),
