@@ -119,9 +119,11 @@ table_grad_kernel(const TgParams p) {
         }
     }
     // Per-tile metadata travels two tiles ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the
-    // window that arrived an iteration ago, the first 64 entries / dictionary ids / gh values of tile i+1.  Read at the
-    // point of use they were two DEPENDENT global round trips per tile (tile_ptr -> tile_pack) in front of a walk that
-    // itself takes well under a microsecond: 56 of the kernel's 92 us at k = 8.
+    // window that arrived an iteration ago, the first 64 entries / dictionary ids / gh values of tile i+1, so that no
+    // dependent global round trip (tile_ptr -> tile_pack) sits in front of a walk.  (Worth ~3 us per launch only: the
+    // walk itself, not its operands' latency, is the critical path.)
+    // (Measured alternatives, k = 8, D = 104: hop-major entry order 90 us, chunks cut at table-row boundaries with plain
+    //  read-modify-write flushes 75 us, this version 62 us - DESIGN.md section 5.)
     struct TileMeta { int beg, end; uint32_t nxt; int uid; float gh[2]; };
     static_assert(kGroups * 2 >= 8, "two gh values per thread cover a tile of up to 8 nodes");
     // window of tile t2: lane 0 fetches its begin, lane 1 its end (kept as a per-lane value on purpose: a wave-uniform
@@ -158,9 +160,9 @@ table_grad_kernel(const TgParams p) {
         rng1 = load_range((int64_t)blockIdx.x + gridDim.x);
     }
     for (int64_t tl = blockIdx.x; tl < num_tiles; tl += gridDim.x) {
-        // Consume this tile's metadata NOW (requested an iteration ago): the wait must sit in front of the loads issued
-        // below for the next tile - a wait placed inside the walk is a vmcnt(0) that also waits for the g rows just
-        // requested for the next tile, i.e. one exposed HBM round trip per tile (56 of 92 us at k = 8).
+        // Consume this tile's metadata NOW (requested an iteration ago): the wait then sits in front of the loads issued
+        // below for the next tile; a wait placed inside the walk would be a vmcnt(0) that also waits for the g rows just
+        // requested for the next tile.
         uint32_t mine = cm.nxt;
         int myuid = cm.uid;                           // lane l: dictionary row of tile row l
         float gh0 = cm.gh[0], gh1 = cm.gh[1];
