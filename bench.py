@@ -106,9 +106,12 @@ def capture_graphs(model, batches, flat_grad):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     pool = None
+    # with a process group alive, its watchdog thread may query events while this thread captures: thread-local capture
+    # mode keeps those calls legal (the captured region itself holds no collective)
+    mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
     for b in batches:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool):
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
             loss = fwd_bwd(model, b, flat_grad)
         pool = g.pool()
         graphs.append((g, loss))
