@@ -341,7 +341,7 @@ struct BwdParams {
 // TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
 //      2 = straight global atomics (tables too large for LDS)
 template <int VEC, int G, bool GCN, int TAB>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 6)
 agg_bwd_kernel(const BwdParams p) {
     const int MODE = p.mode;
     extern __shared__ __attribute__((aligned(16))) float lds_gt[];
@@ -398,8 +398,20 @@ agg_bwd_kernel(const BwdParams p) {
                 }
             }
         };
+        // gfx9 has ONE counter for vector loads and stores and they may complete out of order with respect to each other,
+        // so any wait for a load while a store is pending is a vmcnt(0): storing hop k's row right before waiting for hop
+        // k+1's prefetched rows put a full store round trip on every hop's critical path.  The store is therefore held
+        // back one hop and issued together with the next prefetch (both then share one wait); the epilogue's own operands
+        // (GIN self row, old value of an accumulating slot) are requested one hop ahead for the same reason.
+        V<VEC> pend = V<VEC>::zero(), nself = V<VEC>::zero(), nold = V<VEC>::zero();
+        float* pend_dst = nullptr;
+        auto epi_prefetch = [&](int kk) {
+            if (!CHUNKED || !col_ok) return;
+            if (MODE == KPGNN_MODE_GIN) nself = V<VEC>::load(p.g + (int64_t)kk * p.g_sk + c0 + j * p.g_sn);
+            if (!p.gx && ((p.acc_mask >> kk) & 1u)) nold = V<VEC>::load(p.gxs[kk] + j * p.gx_sn + c0);
+        };
         int end_next = lane_meta ? __shfl(myrp, sg_lane0 + 1) : rp[1];
-        if (CHUNKED) prefetch(0, beg, end_next);
+        if (CHUNKED) { prefetch(0, beg, end_next); epi_prefetch(0); }
         for (int k = 0; k < p.K; ++k) {
             const int end = end_next;
             if (k + 1 < p.K) end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
@@ -415,7 +427,10 @@ agg_bwd_kernel(const BwdParams p) {
                 const int cn = prn;
 #pragma unroll
                 for (int u = 0; u < PF; ++u) cur[u] = pr[u];
-                if (k + 1 < p.K) prefetch(k + 1, end, end_next);
+                if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, nself);      // (this hop's epilogue operands arrived with its rows)
+                if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(nold);
+                if (pend_dst) { pend.store(pend_dst); pend_dst = nullptr; }   // previous hop's result
+                if (k + 1 < p.K) { prefetch(k + 1, end, end_next); epi_prefetch(k + 1); }
 #pragma unroll
                 for (int u = 0; u < PF; ++u)
                     if (u < cn) acc.add(cur[u]);
@@ -492,7 +507,7 @@ agg_bwd_kernel(const BwdParams p) {
             }
             beg = end;
             if (!col_ok) continue;
-            if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, V<VEC>::load(gk + j * p.g_sn));
+            if (!CHUNKED && MODE == KPGNN_MODE_GIN) acc.fma(eps1, V<VEC>::load(gk + j * p.g_sn));
             if (GCN) {
                 V<VEC> self = V<VEC>::load(gk + j * p.g_sn);
                 for (int q = 0; q < VEC; ++q) self.v[q] *= dj * dj;
@@ -503,9 +518,15 @@ agg_bwd_kernel(const BwdParams p) {
                 }
             }
             float* dst = (p.gx ? p.gx + (int64_t)k * p.gx_sk : p.gxs[k]) + j * p.gx_sn + c0;
-            if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(V<VEC>::load(dst));   // one sub-group owns the row: no atomics
-            acc.store(dst);
+            if (CHUNKED) {                                   // (one sub-group owns the row: no atomics)
+                pend = acc;
+                pend_dst = dst;
+            } else {
+                if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(V<VEC>::load(dst));
+                acc.store(dst);
+            }
         }
+        if (pend_dst) pend.store(pend_dst);                  // last hop: overlaps the next node's metadata loads
     }
     if (TAB == 1) {
         __syncthreads();
