@@ -83,7 +83,7 @@ struct FwdParams {
 // FAST: the KP-GIN+ training configuration (GELU epilogue, fused geometric combine, dictionary P, S saved) with its
 // epilogue switches resolved at compile time.
 template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, FAST ? 5 : 4)
 agg_fwd_kernel(const FwdParams p) {
     const int MODE = FAST ? (int)KPGNN_MODE_GINPLUS : p.mode;
     const bool COMBINE = FAST ? true : p.combine != 0;
@@ -189,21 +189,20 @@ agg_fwd_kernel(const FwdParams p) {
             const char* xkb = reinterpret_cast<const char*>(p.x ? p.x + (int64_t)k * p.x_sk : p.xs[k]);   // wave-uniform
             const char* tabb = reinterpret_cast<const char*>(tab);
             if (!GCN) {
-                V<VEC> cur[PF];
-                uint32_t curb[PF];
+                // (sum the prefetched rows first, then reuse their registers for the next hop's prefetch: a copy would
+                //  have to wait for the rows just the same and costs 20 VGPRs, i.e. a wave per SIMD)
                 const int cn = prn;
-#pragma unroll
-                for (int u = 0; u < PF; ++u) { cur[u] = pr[u]; curb[u] = prb[u]; }
-                if (k + 1 < p.K) {
-                    end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
-                    prefetch(k + 1, end, end_next);
-                }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     if (u < cn) {
-                        if (TAB != 0) cur[u].add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(curb[u] + lane_b))));
-                        acc.add(cur[u]);
+                        V<VEC> r = pr[u];
+                        if (TAB != 0) r.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(prb[u] + lane_b))));
+                        acc.add(r);
                     }
+                }
+                if (k + 1 < p.K) {
+                    end_next = lane_meta ? __shfl(myrp, sg_lane0 + k + 2) : rp[k + 2];
+                    prefetch(k + 1, end, end_next);
                 }
                 int pos = beg + cn;
                 while (pos < end) {
@@ -570,12 +569,33 @@ unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
     return (unsigned)(g > 0 ? g : 1);
 }
 
+// Blocks of this kernel instantiation that fit one CU with `lds` bytes of dynamic LDS.  The grids are persistent, so
+// they are sized to ONE resident round: with more blocks than fit, the late starters leave the tail unbalanced
+// (agg_fwd at 6 blocks/CU where 5 fit: 96 vs 85 us), with fewer the CU runs below its occupancy (agg_bwd at 4 of 6:
+// 67 vs 60 us).  Cached per instantiation and LDS size; 0 on failure (the caller then uses its default).
+template <typename Kernel>
+int resident_blocks(Kernel kernel, size_t lds) {
+    // (all instantiations share this function's statics - they have the same pointer type - so the small cache is keyed
+    //  by the kernel's address too)
+    struct Entry { const void* k; size_t lds; int nb; };
+    static thread_local Entry cache[8] = {};
+    static thread_local int next = 0;
+    for (const Entry& e : cache)
+        if (e.k == (const void*)kernel && e.lds == lds) return e.nb;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    cache[next] = Entry{(const void*)kernel, lds, nb};
+    next = (next + 1) % 8;
+    return nb;
+}
+
 template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
 int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
-    const unsigned grid = pick_grid(tiles, 8);
     if (lds > 64 * 1024)
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds));
+    const int nb = resident_blocks(agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds);
+    const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
     hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB, FAST>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
     return KPGNN_OK;
@@ -598,9 +618,10 @@ int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
 template <int VEC, int G, bool GCN, int TAB>
 int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
-    const unsigned grid = pick_grid(tiles, 4);
     if (lds > 64 * 1024)
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>, lds));
+    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB>, lds);
+    const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
     hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_bwd_kernel");
     return KPGNN_OK;
