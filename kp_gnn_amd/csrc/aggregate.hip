@@ -569,32 +569,12 @@ unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
     return (unsigned)(g > 0 ? g : 1);
 }
 
-// Blocks of this kernel instantiation that fit one CU with `lds` bytes of dynamic LDS.  The grids are persistent, so
-// they are sized to ONE resident round: with more blocks than fit, the late starters leave the tail unbalanced
-// (agg_fwd at 6 blocks/CU where 5 fit: 96 vs 85 us), with fewer the CU runs below its occupancy (agg_bwd at 4 of 6:
-// 67 vs 60 us).  Cached per instantiation and LDS size; 0 on failure (the caller then uses its default).
-template <typename Kernel>
-int resident_blocks(Kernel kernel, size_t lds) {
-    // (all instantiations share this function's statics - they have the same pointer type - so the small cache is keyed
-    //  by the kernel's address too)
-    struct Entry { const void* k; size_t lds; int nb; };
-    static thread_local Entry cache[8] = {};
-    static thread_local int next = 0;
-    for (const Entry& e : cache)
-        if (e.k == (const void*)kernel && e.lds == lds) return e.nb;
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-    cache[next] = Entry{(const void*)kernel, lds, nb};
-    next = (next + 1) % 8;
-    return nb;
-}
-
 template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
 int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     if (lds > 64 * 1024)
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds));
-    const int nb = resident_blocks(agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds);
+    const int nb = resident_blocks(agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, kBlock, lds);
     const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
     hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB, FAST>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
@@ -620,7 +600,7 @@ int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     if (lds > 64 * 1024)
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>, lds));
-    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB>, lds);
+    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB>, kBlock, lds);
     const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
     hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_bwd_kernel");

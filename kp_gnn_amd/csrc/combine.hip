@@ -157,10 +157,10 @@ combine_bwd_kernel(const CbParams p) {
 }
 
 // grid: <= 8 blocks per CU, (grid * sub-groups per block) a multiple of K
-int cb_grid(int N, int K, int G) {
+int cb_grid(int N, int K, int G, int per_cu) {
     const int nodes = kBlock / G;
     const int64_t rows = (int64_t)N * K;
-    int64_t g = (int64_t)device_facts().cu_count * 8;
+    int64_t g = (int64_t)device_facts().cu_count * (per_cu >= 1 && per_cu <= 8 ? per_cu : 8);
     const int64_t need = (rows + nodes - 1) / nodes;
     if (g > need) g = need;
     // smallest m with (m * nodes) % K == 0
@@ -185,15 +185,18 @@ int cb_shape(const kpgnn_combine_bwd_desc* d, int* vec, int* g) {
 }
 
 template <int VEC, int G, int ACT, bool WGT>
-int cb_launch2(const CbParams& p, int grid, size_t lds, hipStream_t s) {
+int cb_launch2(const CbParams& p, int* grid_out, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, ACT, WGT>, lds));
+    // grid-stride kernel: one resident round (kpgnn_common.h, resident_blocks)
+    const int grid = cb_grid(p.N, p.K, G, resident_blocks(combine_bwd_kernel<VEC, G, ACT, WGT>, kBlock, lds));
+    *grid_out = grid;
     hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, ACT, WGT>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("combine_bwd_kernel");
     return KPGNN_OK;
 }
 
 template <int VEC, int G>
-int cb_launch(const CbParams& p, int grid, hipStream_t s) {
+int cb_launch(const CbParams& p, int* grid, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)(((p.lds_ptab + 3) & ~3) + (p.slab ? (kBlock / G) * p.D : 0));
     const int act = p.mode == KPGNN_MODE_GINPLUS ? 1 : (p.mode == KPGNN_MODE_GCN ? 2 : 0);
     if (p.slab) {
@@ -232,7 +235,7 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     p.gout = d->gout; p.go_sn = d->go_sn; p.go_sk = d->go_sk; p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     p.g = d->g; p.gv = d->gv; p.slab = nullptr;
-    const int grid = cb_grid(d->N, d->K, g);
+    int grid = cb_grid(d->N, d->K, g, 8);           // upper bound (workspace check); the launcher picks the real one
     p.lds_ptab = 0;
     { const char* e = getenv("KPGNN_CB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     if (d->gtheta) {
@@ -243,7 +246,7 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
         if (p.ptab && p.uid && d->n_dict > 0 && (size_t)d->n_dict * d->D * sizeof(float) <= 16 * 1024) p.lds_ptab = d->n_dict * d->D;
     }
     hipStream_t s = (hipStream_t)stream;
-#define KP_CB(V, GG) rc = cb_launch<V, GG>(p, grid, s); break
+#define KP_CB(V, GG) rc = cb_launch<V, GG>(p, &grid, s); break
     switch (vec * 100 + g) {
         case 404: KP_CB(4, 4); case 408: KP_CB(4, 8); case 416: KP_CB(4, 16); case 432: KP_CB(4, 32); case 464: KP_CB(4, 64);
         case 204: KP_CB(2, 4); case 208: KP_CB(2, 8); case 216: KP_CB(2, 16); case 232: KP_CB(2, 32); case 264: KP_CB(2, 64);

@@ -104,4 +104,25 @@ struct XcdTileWalk {
     __device__ void next() { cur += step; }
 };
 
+// Blocks of a kernel instantiation that fit one CU with `lds` bytes of dynamic LDS.  Persistent grids are sized
+// to ONE resident round: with more blocks than fit, the late starters leave the tail unbalanced
+// (agg_fwd at 6 blocks/CU where 5 fit: 96 vs 85 us), with fewer the CU runs below its occupancy (agg_bwd at 4 of 6:
+// 67 vs 60 us).  Cached per instantiation and LDS size; 0 on failure (the caller then uses its default).
+template <typename Kernel>
+int resident_blocks(Kernel kernel, int block_threads, size_t lds) {
+    // (all instantiations share this function's statics - they have the same pointer type - so the small cache is keyed
+    //  by the kernel's address too)
+    struct Entry { const void* k; size_t lds; int threads, nb; };
+    static thread_local Entry cache[16] = {};
+    static thread_local int next = 0;
+    for (const Entry& e : cache)
+        if (e.k == (const void*)kernel && e.lds == lds && e.threads == block_threads) return e.nb;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    cache[next] = Entry{(const void*)kernel, lds, block_threads, nb};
+    next = (next + 1) % 16;
+    return nb;
+}
+
+
 }  // namespace kpgnn
