@@ -637,16 +637,21 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
     p.slab = (float*)d->workspace;
     { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    // one resident round: the plan sizes the grid by LDS alone, the registers (accumulators of all row tiles) usually
+    // allow fewer blocks per CU - a smaller grid also means a smaller slab to write and reduce
+    int grid = pl.grid;
 #define KP_TGM(IT, MTV) do { \
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_mfma_kernel<IT, MTV>, pl.lds)); \
-        hipLaunchKernelGGL((table_grad_mfma_kernel<IT, MTV>), dim3(pl.grid), dim3(kTgmThreads), pl.lds, s, p); } while (0)
+        const int nb = resident_blocks(table_grad_mfma_kernel<IT, MTV>, kTgmThreads, pl.lds); \
+        if (nb > 0 && (int64_t)nb * device_facts().cu_count < grid) grid = nb * device_facts().cu_count; \
+        hipLaunchKernelGGL((table_grad_mfma_kernel<IT, MTV>), dim3(grid), dim3(kTgmThreads), pl.lds, s, p); } while (0)
     if (pl.maxit == 1) { if (pl.mtmax == 4) KP_TGM(1, 4); else if (pl.mtmax == 8) KP_TGM(1, 8); else KP_TGM(1, 16); }
     else if (pl.maxit == 2) { if (pl.mtmax == 4) KP_TGM(2, 4); else if (pl.mtmax == 8) KP_TGM(2, 8); else KP_TGM(2, 16); }
     else { if (pl.mtmax == 4) KP_TGM(4, 4); else KP_TGM(4, 8); }
 #undef KP_TGM
     KPGNN_LAUNCH_CHECK("table_grad_mfma_kernel");
     *handled = true;
-    return slab_reduce(p.slab, pl.grid * pl.KQ, (int64_t)pl.R * p.D, d->gtable0, (int64_t)n0 * p.D, d->gtablek,
+    return slab_reduce(p.slab, grid * pl.KQ, (int64_t)pl.R * p.D, d->gtable0, (int64_t)n0 * p.D, d->gtablek,
                        (int64_t)nk * p.D, d->gdict, s);
 }
 
