@@ -422,17 +422,16 @@ agg_bwd_kernel(const BwdParams p) {
             //  broadcasts them and adds the lane's column offset)
             const char* gkb = reinterpret_cast<const char*>(p.g + (int64_t)k * p.g_sk);   // wave-uniform
             if (CHUNKED) {
-                V<VEC> cur[PF];
+                // (the prefetched rows are summed in place and their registers reused for the next prefetch: a copy would
+                //  wait for them just the same)
                 const int cn = prn;
 #pragma unroll
-                for (int u = 0; u < PF; ++u) cur[u] = pr[u];
+                for (int u = 0; u < PF; ++u)
+                    if (u < cn) acc.add(pr[u]);
                 if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, nself);      // (this hop's epilogue operands arrived with its rows)
                 if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(nold);
                 if (pend_dst) { pend.store(pend_dst); pend_dst = nullptr; }   // previous hop's result
                 if (k + 1 < p.K) { prefetch(k + 1, end, end_next); epi_prefetch(k + 1); }
-#pragma unroll
-                for (int u = 0; u < PF; ++u)
-                    if (u < cn) acc.add(cur[u]);
                 int pos = beg + cn;
                 while (pos < end) {
                     if (pos >= cbase + G) {
