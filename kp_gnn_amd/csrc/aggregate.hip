@@ -307,8 +307,8 @@ agg_fwd_kernel(const FwdParams p) {
             if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
             else if (FAST || p.uid) {
                 const int u = lane_meta ? uk : p.uid[i * p.uid_stride + k];
-                if (u != last_u) { prow = V<VEC>::load(ptp + (int64_t)u * D + c0); last_u = u; }  // mostly one row
-                v.add(prow);
+                if (FAST) v.add(V<VEC>::load(ptp + (int64_t)u * D + c0));        // (dictionary staged in LDS: no register copy)
+                else { if (u != last_u) { prow = V<VEC>::load(ptp + (int64_t)u * D + c0); last_u = u; } v.add(prow); }  // mostly one row
             }
             if (MODE == KPGNN_MODE_GIN) { V<VEC> xs = V<VEC>::load(xk + i * p.x_sn); xs.add(xb); v.fma(eps1, xs); }
             if (COMBINE) {
