@@ -113,14 +113,14 @@ int resident_blocks(Kernel kernel, int block_threads, size_t lds) {
     // (all instantiations share this function's statics - they have the same pointer type - so the small cache is keyed
     //  by the kernel's address too)
     struct Entry { const void* k; size_t lds; int threads, nb; };
-    static thread_local Entry cache[16] = {};
+    static thread_local Entry cache[64] = {};
     static thread_local int next = 0;
     for (const Entry& e : cache)
         if (e.k == (const void*)kernel && e.lds == lds && e.threads == block_threads) return e.nb;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
     cache[next] = Entry{(const void*)kernel, lds, block_threads, nb};
-    next = (next + 1) % 16;
+    next = (next + 1) % 64;
     return nb;
 }
 
