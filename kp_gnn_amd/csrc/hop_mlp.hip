@@ -662,12 +662,19 @@ extern "C" int kpgnn_hop_mlp_fwd(const kpgnn_hop_mlp_desc* d, kpgnn_stream_t str
     HmParams p;
     hm_fill(d, pl, &p);
     hipStream_t s = (hipStream_t)stream;
+    // (persistent tile loop: the grid is one resident round - the plan sizes it by LDS, the registers may allow fewer)
+    auto one_round = [&](int nb, int grid) {
+        const int64_t cap = (int64_t)nb * device_facts().cu_count;
+        return nb > 0 && cap < grid ? (int)cap : grid;
+    };
     if (pl.T == 1) {
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)hop_mlp_fwd_kernel<1>, pl.lds_fwd));
-        hipLaunchKernelGGL(hop_mlp_fwd_kernel<1>, dim3(pl.grid_fwd), dim3(kHmThreads), pl.lds_fwd, s, p);
+        const int grid = one_round(resident_blocks(hop_mlp_fwd_kernel<1>, kHmThreads, pl.lds_fwd), pl.grid_fwd);
+        hipLaunchKernelGGL(hop_mlp_fwd_kernel<1>, dim3(grid), dim3(kHmThreads), pl.lds_fwd, s, p);
     } else {
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)hop_mlp_fwd_kernel<2>, pl.lds_fwd));
-        hipLaunchKernelGGL(hop_mlp_fwd_kernel<2>, dim3(pl.grid_fwd), dim3(kHmThreads), pl.lds_fwd, s, p);
+        const int grid = one_round(resident_blocks(hop_mlp_fwd_kernel<2>, kHmThreads, pl.lds_fwd), pl.grid_fwd);
+        hipLaunchKernelGGL(hop_mlp_fwd_kernel<2>, dim3(grid), dim3(kHmThreads), pl.lds_fwd, s, p);
     }
     KPGNN_LAUNCH_CHECK("hop_mlp_fwd_kernel");
     return KPGNN_OK;
