@@ -184,7 +184,8 @@ typedef struct kpgnn_agg_bwd_desc {
      * stride gx_sn (the backward of the per-hop inputs above: no [N,k,D] tensor to slice up afterwards). */
     float* gx_slot[16];
     /* Bit k set: ADD the gradient of hop slot k to what gx_slot[k] already holds (a state that several layers read as
-     * a slot collects its gradient in one buffer instead of one tensor per reader plus an add each). */
+     * a slot collects its gradient in one buffer instead of one tensor per reader plus an add each).  Two hop slots of
+     * one call must not share a buffer when either accumulates (KPGNN_EINVAL). */
     uint32_t accumulate_mask;
 } kpgnn_agg_bwd_desc;
 

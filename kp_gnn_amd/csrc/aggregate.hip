@@ -738,6 +738,12 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         if (p.gxs[k] && (!slot_align || ((uintptr_t)p.gxs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.gxs[k];
     }
     p.acc_mask = d->gx ? 0u : d->accumulate_mask;
+    // (the kernel requests the old value of an accumulating slot one hop ahead and stores a hop's result one hop late:
+    //  two hops of one launch must not share a slot buffer)
+    for (int a = 0; a < d->K && a < 16; ++a)
+        for (int b = a + 1; b < d->K && b < 16; ++b)
+            if (p.gxs[a] && p.gxs[a] == p.gxs[b] && (((p.acc_mask >> a) | (p.acc_mask >> b)) & 1u))
+                return fail(KPGNN_EINVAL, "aggregate_bwd: hop slots %d and %d share one gradient buffer with accumulate_mask set", a, b);
     if ((uint64_t)d->N * (uint64_t)d->g_sn * 4u >= (1ull << 32))
         return fail(KPGNN_ELIMIT, "aggregate_bwd: N * g row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->g_sn);
     const int vec = pick_vec(d->D, {d->g, d->gx ? (const void*)d->gx : slot_align}, {d->g_sn, d->g_sk, d->gx_sn, d->gx ? d->gx_sk : 0});
