@@ -345,6 +345,32 @@ def test_table_gather_sum_vs_torch(D, R_sizes):
     _close(bd.grad, br.grad, "gbias", atol=3e-5)
 
 
+def test_aggregate_bwd_accumulating_slots_and_alias_rejection():
+    """accumulate_mask: the kernel adds a hop slot's gradient into a caller buffer (the old value is requested a hop
+    ahead, the result stored a hop late) - equals fresh buffers + add; two hops sharing one accumulating buffer in a
+    single call are refused (KPGNN_EINVAL)."""
+    from kp_gnn_amd import ops, _lib
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    N, E, K, D = 301, 4000, 5, 24
+    ei, ea = _random_khop(N, E, K, seed=77)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    gen = torch.Generator().manual_seed(3)
+    g = torch.randn(N, K, D, generator=gen).to(dev)
+    fresh, _, _ = ops.aggregate_bwd_raw(csr, K, ops.MODE_GINPLUS, g, None, 0, 0, False, slots=True)
+    olds = [torch.randn(N, D, generator=gen).to(dev) if k % 2 == 0 else None for k in range(K)]
+    bufs = [o.clone() if o is not None else None for o in olds]
+    acc, _, _ = ops.aggregate_bwd_raw(csr, K, ops.MODE_GINPLUS, g, None, 0, 0, False, slots=True, slot_bufs=bufs)
+    torch.cuda.synchronize()
+    for k in range(K):
+        want = fresh[k] + olds[k] if olds[k] is not None else fresh[k]
+        _close(acc[k], want.cpu(), f"slot {k}", atol=1e-5)
+    shared = torch.zeros(N, D, device=dev)
+    with pytest.raises(_lib.KpgnnError):
+        ops.aggregate_bwd_raw(csr, K, ops.MODE_GINPLUS, g, None, 0, 0, False, slots=True,
+                              slot_bufs=[shared, shared] + [None] * (K - 2))
+
+
 @pytest.mark.parametrize("N,E,K,ncode", [(203, 3000, 6, 9), (64, 20000, 3, 3), (10, 0, 4, 3)])
 def test_tile_entry_list_merges_the_csr_pairs(N, E, K, ncode):
     """The third CSR ordering: one entry per distinct (node, hop, code) with its multiplicity, sorted by
