@@ -47,6 +47,10 @@ template <int VEC> struct V {
         for (int i = 0; i < VEC; ++i) f[i] = v[i];
         *reinterpret_cast<typename Vec<VEC>::T*>(p) = t;
     }
+    // streaming store (nt): for rows nobody re-reads in this launch - they should not displace the gathered rows in L2
+    __device__ __forceinline__ void store_stream(float* p) const {
+        for (int i = 0; i < VEC; ++i) __builtin_nontemporal_store(v[i], p + i);
+    }
     __device__ __forceinline__ void add(const V& o) { for (int i = 0; i < VEC; ++i) v[i] += o.v[i]; }
     __device__ __forceinline__ void fma(float s, const V& o) { for (int i = 0; i < VEC; ++i) v[i] = fmaf(s, o.v[i], v[i]); }
 };
@@ -301,7 +305,7 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if ((FAST || p.pre) && !(p.dbg & 4)) v.store(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if ((FAST || p.pre) && !(p.dbg & 4)) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
             if (MODE == KPGNN_MODE_GINPLUS && !(p.dbg & 2)) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
@@ -315,10 +319,10 @@ agg_fwd_kernel(const FwdParams p) {
                 const V<VEC> th = V<VEC>::load(thp + k * D + c0);
                 for (int q = 0; q < VEC; ++q) hsum.v[q] = fmaf(th.v[q], v.v[q], hsum.v[q]);
             } else {
-                v.store(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
+                v.store_stream(p.out + i * p.o_sn + (int64_t)k * p.o_sk + c0);
             }
         }
-        if (COMBINE && col_ok) hsum.store(p.hout + i * (int64_t)D + c0);
+        if (COMBINE && col_ok) hsum.store_stream(p.hout + i * (int64_t)D + c0);
     }
 }
 
@@ -430,7 +434,7 @@ agg_bwd_kernel(const BwdParams p) {
                     if (u < cn) acc.add(pr[u]);
                 if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, nself);      // (this hop's epilogue operands arrived with its rows)
                 if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(nold);
-                if (pend_dst) { pend.store(pend_dst); pend_dst = nullptr; }   // previous hop's result
+                if (pend_dst) { pend.store_stream(pend_dst); pend_dst = nullptr; }   // previous hop's result
                 if (k + 1 < p.K) { prefetch(k + 1, end, end_next); epi_prefetch(k + 1); }
                 int pos = beg + cn;
                 while (pos < end) {
@@ -524,7 +528,7 @@ agg_bwd_kernel(const BwdParams p) {
                 acc.store(dst);
             }
         }
-        if (pend_dst) pend.store(pend_dst);                  // last hop: overlaps the next node's metadata loads
+        if (pend_dst) pend.store_stream(pend_dst);                  // last hop: overlaps the next node's metadata loads
     }
     if (TAB == 1) {
         __syncthreads();
