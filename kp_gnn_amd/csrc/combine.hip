@@ -24,6 +24,9 @@ template <int VEC> __device__ __forceinline__ void ldv(const float* p, float (&v
     typename VT<VEC>::T t = *reinterpret_cast<const typename VT<VEC>::T*>(p);
     for (int q = 0; q < VEC; ++q) v[q] = reinterpret_cast<const float*>(&t)[q];
 }
+template <int VEC> __device__ __forceinline__ void ldv_stream(const float* p, float (&v)[VEC]) {   // read-once stream (nt)
+    for (int q = 0; q < VEC; ++q) v[q] = __builtin_nontemporal_load(p + q);
+}
 template <int VEC> __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
     typename VT<VEC>::T t;
     for (int q = 0; q < VEC; ++q) reinterpret_cast<float*>(&t)[q] = v[q];
@@ -94,7 +97,7 @@ combine_bwd_kernel(const CbParams p) {
                 for (int q = 0; q < VEC; ++q) { s[u][q] = 0.f; gvv[u][q] = 0.f; ghv[u][q] = 0.f; pv[u][q] = 0.f; }
                 u_id[u] = -1;
                 if (ru < R) {
-                    ldv<VEC>(pre + ru * D + c0, s[u]);
+                    ldv_stream<VEC>(pre + ru * D + c0, s[u]);
                     if (fused) ldv<VEC>(p.gh + iu * D + c0, ghv[u]);
                     else ldv<VEC>(p.gout + iu * p.go_sn + (int64_t)k * p.go_sk + c0, gvv[u]);
                     if (want_gt) {
