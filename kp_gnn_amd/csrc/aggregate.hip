@@ -384,9 +384,9 @@ agg_bwd_kernel(const BwdParams p) {
         uint32_t coff = 0;
         if (CHUNKED) {
             const int idx = cbase + sl;
-            // (streaming load: the pair list is read once and should not displace gathered rows in L2 - measured 54 -> 51 us;
-            //  the same hint on the forward's col / code loads was slightly slower, 69 -> 72 us)
-            if (idx < end_all) coff = (uint32_t)__builtin_nontemporal_load(p.col + idx) * grow_b;
+            // (a streaming hint on these pair-list loads: within noise at D = 104, 32 -> 40 us at D = 13; on the forward's
+            //  col / code loads 69 -> 72 us - not used)
+            if (idx < end_all) coff = (uint32_t)p.col[idx] * grow_b;
         }
         constexpr int PF = G >= 32 ? 4 : 2;
         V<VEC> pr[PF];
@@ -444,7 +444,7 @@ agg_bwd_kernel(const BwdParams p) {
                         cbase += G;
                         const int idx = cbase + sl;
                         coff = 0;
-                        if (idx < end_all) coff = (uint32_t)__builtin_nontemporal_load(p.col + idx) * grow_b;
+                        if (idx < end_all) coff = (uint32_t)p.col[idx] * grow_b;
                     }
                     const int lim = min(end, cbase + G) - cbase;
                     int t = pos - cbase;
