@@ -62,12 +62,10 @@ def fwd_bwd(model, batch, flat_grad):
     loss = (score.squeeze() - batch.y.squeeze()).abs().mean()  # train_ZINC.py:42
     params, views = dp.grad_views(model)
     grads = torch.autograd.grad(loss, params, allow_unused=True)
-    ops_dense.join_wgrad_stream()   # (weight-gradient kernels may have run on the side stream)
     used = [(v, g) for v, g in zip(views, grads) if g is not None]
     torch._foreach_copy_([v for v, _ in used], [g for _, g in used])
-    for v, g in zip(views, grads):
-        if g is None:
-            v.zero_()   # parameter without gradient this step (e.g. the never-trained path-encoding table, Q1)
+    # (parameters without a gradient - e.g. the never-trained path-encoding tables, Q1 - keep the zeros the flat bucket
+    #  was created with: nothing ever writes their views)
     return loss
 
 
@@ -214,8 +212,6 @@ def main():
     from kp_gnn_amd.batch import synthetic_zinc_batch
     global dp, ops_dense
     from kp_gnn_amd import dp, ops_dense
-    # (measured: running the weight-gradient kernels on a side stream is slower inside the replayed graph, 7.00 vs 6.73 ms)
-    ops_dense.set_wgrad_overlap(os.environ.get("KPGNN_WGRAD_OVERLAP", "0") == "1")
 
     threads = max(1, usable_cpus() // max(1, min(world, 8)))
     torch.set_num_threads(threads)
@@ -253,15 +249,11 @@ def main():
     torch.cuda.synchronize()
     graphs = None
     if not args.no_graph:
-        try:
-            graphs = capture_graphs(model, batches, flat_grad)
-            for i in range(len(batches)):  # one replayed step per graph before timing
-                train_step(model, batches[i], opt, flat_grad, world, graphs[i])
-            torch.cuda.synchronize()
-        except Exception as e:  # capture is an optimisation of the launch path only
-            graphs = None
-            if rank == 0:
-                log(f"hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+        # (a capture failure is an error, not a silent downgrade to eager launches: --no-graph asks for those)
+        graphs = capture_graphs(model, batches, flat_grad)
+        for i in range(len(batches)):  # one replayed step per graph before timing
+            train_step(model, batches[i], opt, flat_grad, world, graphs[i])
+        torch.cuda.synchronize()
     if rank == 0:
         log(f"{args.warmup} warm-up steps done; launch mode: {'hipGraph replay' if graphs else 'eager'}")
     barrier()

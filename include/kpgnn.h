@@ -83,19 +83,6 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
                     int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                     void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
-/* Component-aligned node tiles for the LDS-staged aggregation kernels.  A "cut" after node i exists when no
- * active pair connects a node <= i with a node > i (collated batches: every graph boundary is a cut).  Consecutive
- * components are packed greedily into tiles of at most `node_cap` nodes and `pair_cap` active pairs (all K_csr
- * hops); a tile therefore only gathers rows of its OWN node range, which a workgroup can stage in LDS once.
- * Components larger than the caps are chopped into node_cap chunks flagged 1 (their gathers leave the tile: the
- * kernels then read those rows from global memory).  Outputs (device): tile_start int32[<= N+1] (node offsets,
- * tile_start[T] = N), tile_flag uint8[<= N], num_tiles int32[1].  Workspace: N int32. */
-int kpgnn_csr_component_tiles(const int32_t* rowptr_dst, const int32_t* col_dst, const int32_t* rowptr_src,
-                              const int32_t* col_src, int64_t N, int32_t K, int32_t node_cap, int32_t pair_cap,
-                              int32_t* tile_start, uint8_t* tile_flag, int32_t* num_tiles,
-                              void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
-size_t kpgnn_csr_component_tiles_workspace_bytes(int64_t N);
-
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
@@ -145,12 +132,6 @@ typedef struct kpgnn_agg_fwd_desc {
     const float* ptab;
     const int32_t* uid;
     int64_t uid_stride;
-    /* Optional component tiles (kpgnn_csr_component_tiles): with them the launch takes the LDS-staged kernel
-     * (rows, ids and row pointers of a tile staged in LDS; HBM sees only the algorithmic bytes) when the
-     * shape qualifies (D % 4 == 0, 16-B aligned operands, not GCN), else the global-gather kernel. */
-    const int32_t* tile_start;
-    const uint8_t* tile_flag;
-    int32_t num_tiles, tile_node_cap, tile_pair_cap;
     /* Per-hop inputs (used when x == NULL): hop slot k reads x_slot[k], a [N,D] matrix with row stride x_sn.
      * GNNPlus stacks the previous layers' states into [N,k,H] with torch.cat every layer (models/GNNs.py:413-418);
      * with slots the kernel reads the k states where they are and the copy disappears.  K <= 16. */
@@ -219,18 +200,10 @@ typedef struct kpgnn_table_grad_desc {
     float* gdict;               /* device [n_dict, D] */
     void* workspace;            /* device, >= kpgnn_table_grad_workspace_bytes(...) */
     size_t workspace_bytes;
-    /* Optional fused backward pre-pass (fuse_pre != NULL; needs theta, gh; D % 4 == 0, D <= 128, K <= 8): g is not
-     * read but COMPUTED tile by tile as theta[k,:]*gh[i,:]*act'(S[i,k,:]) from S = fuse_pre (kpgnn_combine_bwd's
-     * arithmetic, act by fuse_mode), written to fuse_g for kpgnn_aggregate_bwd, and, when gtheta != NULL, the
-     * theta gradient sum_i gh*(act(S)+P) (P from the dictionary fuse_ptab/uid, or 0) is reduced alongside. */
-    const float* fuse_pre;      /* device [N,K,D] contiguous */
-    float* fuse_g;              /* device [N,K,D] contiguous (output) */
-    const float* fuse_ptab;     /* device [n_dict, D] or NULL */
-    float* gtheta;              /* device [K, D] (output) or NULL */
-    int32_t fuse_mode;          /* KPGNN_MODE_* */
-    /* Longest (node, hop) segment of the CSR, or 0 when unknown.  1..256 allows the wide-row kernel that runs the count
-     * matrix product on the bf16 matrix cores (g split exactly into three bf16 parts; counts must be exact in bf16). */
-    int32_t max_pairs_per_segment;
+    /* Kernel choice: 0 = automatic (narrow rows D <= 32 and K > 8 go to the count-matrix product on the matrix cores,
+     * wide rows to the register walk), 1 = force the walk, 2 = force the count-matrix kernel.  The parity tests
+     * compare the two. */
+    int32_t kernel;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,

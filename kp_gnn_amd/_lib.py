@@ -27,8 +27,6 @@ class AggFwdDesc(ctypes.Structure):
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
-        ("tile_start", c_vp), ("tile_flag", c_vp), ("num_tiles", c_i32), ("tile_node_cap", c_i32),
-        ("tile_pair_cap", c_i32),
         ("x_slot", c_vp * 16), ("n_dict", c_i32),
     ]
 
@@ -55,8 +53,7 @@ class TableGradDesc(ctypes.Structure):
         ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp),
         ("gtable0", c_vp), ("gtablek", c_vp), ("gdict", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
-        ("fuse_pre", c_vp), ("fuse_g", c_vp), ("fuse_ptab", c_vp), ("gtheta", c_vp), ("fuse_mode", c_i32),
-        ("max_pairs_per_segment", c_i32),
+        ("kernel", c_i32),
     ]
 
 
@@ -144,9 +141,6 @@ SIGNATURES = {
     "kpgnn_csr_build": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_i64,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
                                        c_vp, ctypes.c_size_t, c_vp]),
-    "kpgnn_csr_component_tiles": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
-                                                 c_vp, ctypes.c_size_t, c_vp]),
-    "kpgnn_csr_component_tiles_workspace_bytes": (ctypes.c_size_t, [c_i64]),
     "kpgnn_aggregate_fwd": (ctypes.c_int, [ctypes.POINTER(AggFwdDesc), c_vp]),
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
     "kpgnn_table_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 7),

@@ -96,7 +96,7 @@ class EmbeddingEncoder(nn.Module):
         self.init_proj.reset_parameters()
 
     def forward(self, data):
-        if data.x.is_cuda and data.x.dtype in (torch.int64, torch.int32):
+        if data.x.is_cuda:   # (host-sync-free backward: hipGraph-capturable, unlike nn.Embedding's)
             return embedding_rows(self.init_proj.weight, data.x)
         return self.init_proj(data.x)
 
@@ -131,7 +131,11 @@ class FeatureConcatEncoder(nn.Module):
         self.proj.reset_parameters()
 
     def forward(self, x):
-        cols = [emb(x[..., i]) for i, emb in enumerate(self.embedding_list)]
+        if x.is_cuda:
+            cols = [embedding_rows(emb.weight, x[..., i].contiguous(), padding_idx=emb.padding_idx)
+                    for i, emb in enumerate(self.embedding_list)]
+        else:
+            cols = [emb(x[..., i]) for i, emb in enumerate(self.embedding_list)]
         return self.proj(torch.cat(cols, dim=-1))
 
 

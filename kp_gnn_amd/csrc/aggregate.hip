@@ -15,7 +15,6 @@
 // HBM-bound: per launch the algorithmic traffic is x + P + out (+pre) once, ids/codes once, tables once
 // (DESIGN.md "Algorithmic bytes").  The gather re-reads (A*D*4 bytes) are meant to be served by L2:
 // tiles of consecutive nodes (= same graph) are walked per XCD (kpgnn_common.h XcdTileWalk).
-#include <cstdlib>
 #include <initializer_list>
 
 #include "kpgnn_common.h"
@@ -79,7 +78,6 @@ struct FwdParams {
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     const float* xs[16];        // per-hop inputs (x == NULL)
     int lds_theta, lds_ptab;    // floats of theta / ptab staged in LDS behind the code tables (TAB == 1), 0 = read from global
-    int dbg;                    // KPGNN_AGG_DEBUG ablation bits (experiments only): 1 every pair reads row 0, 2 no GELU, 4 no pre store
 };
 
 // TAB: 0 = no tables, 1 = tables in LDS, 2 = tables read from global (too large for LDS).
@@ -152,7 +150,6 @@ agg_fwd_kernel(const FwdParams p) {
             if (idx < end_all) {
                 coff = (uint32_t)p.col[idx] * xrow_b;
                 if (TAB != 0) ctab = (uint32_t)p.code[idx] * trow_b;
-                if (p.dbg & 1) coff = 0;
             }
         }
         // Rows of the NEXT hop's first pairs are requested before the current hop is summed and finished, so the one
@@ -305,8 +302,8 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if ((FAST || p.pre) && !(p.dbg & 4)) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
-            if (MODE == KPGNN_MODE_GINPLUS && !(p.dbg & 2)) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
+            if (FAST || p.pre) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
             else if (FAST || p.uid) {
@@ -567,7 +564,6 @@ int pick_group(int lanes_needed) {
 }
 
 unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
-    if (const char* e = getenv("KPGNN_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) blocks_per_cu = v; }
     const int64_t cap = (int64_t)device_facts().cu_count * blocks_per_cu;
     int64_t g = num_tiles < cap ? num_tiles : cap;
     if (g >= kNumXcd) g = g / kNumXcd * kNumXcd;  // XcdTileWalk wants a multiple of 8
@@ -593,7 +589,7 @@ int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
         case 0: return gcn ? launch_fwd<VEC, G, true, 0>(p, 0, s) : launch_fwd<VEC, G, false, 0>(p, 0, s);
         case 1: {
             if (gcn) return launch_fwd<VEC, G, true, 1>(p, lds, s);
-            const bool fast = p.mode == KPGNN_MODE_GINPLUS && p.combine && !p.periph && p.uid && p.ptab && p.pre && !p.dbg;
+            const bool fast = p.mode == KPGNN_MODE_GINPLUS && p.combine && !p.periph && p.uid && p.ptab && p.pre;
             return fast ? launch_fwd<VEC, G, false, 1, true>(p, lds, s) : launch_fwd<VEC, G, false, 1>(p, lds, s);
         }
         default: return gcn ? launch_fwd<VEC, G, true, 2>(p, 0, s) : launch_fwd<VEC, G, false, 2>(p, 0, s);
@@ -636,8 +632,6 @@ int launch_bwd_mode(const BwdParams& p, int tab, size_t lds, hipStream_t s) {
 }  // namespace
 }  // namespace kpgnn
 
-namespace kpgnn { int launch_agg_fwd_lds(const kpgnn_agg_fwd_desc* d, hipStream_t s); }
-
 using namespace kpgnn;
 
 extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream) {
@@ -661,11 +655,6 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->table0 && d->n_code0 >= 1 && (d->K == 1 || (d->tablek && d->n_codek >= 1)),
                       "aggregate_fwd: missing embedding tables");
     KPGNN_REQUIRE(d->periph || !d->uid || (d->ptab && d->uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
-    if (d->x && d->tile_start && d->tile_flag && d->num_tiles > 0 && d->tile_node_cap > 0 && d->tile_pair_cap > 0 &&
-        !getenv("KPGNN_NO_LDS_AGG")) {
-        const int rc = launch_agg_fwd_lds(d, (hipStream_t)stream);
-        if (rc != KPGNN_ELIMIT) return rc;   // ELIMIT: shape not covered -> global-gather kernel below
-    }
     if (d->use_tables) {
         KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || (d->n_code0 >= 2 && (d->K == 1 || d->n_codek >= 2)),
                       "aggregate_fwd: GCN needs code row 1 (self loop) in both tables");
@@ -674,7 +663,6 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     }
     FwdParams p;
     p.lds_theta = p.lds_ptab = 0;
-    { const char* e = getenv("KPGNN_AGG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     if (tab == 1) {      // small side tables behind the code tables (keeps >= 4 blocks of 256 threads per CU)
         lds = (lds + 15) & ~(size_t)15;
         const size_t cap = 36 * 1024;
@@ -692,11 +680,12 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     KPGNN_REQUIRE(p.uid == nullptr || (p.ptab != nullptr && p.uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
-    const void* slot_align = nullptr;   // the least aligned per-hop input decides the vector width
+    uintptr_t slot_bits = 0;            // low address bits of ALL per-hop inputs OR-ed: the least aligned one decides the vector width
     for (int k = 0; k < 16; ++k) {
         p.xs[k] = (!d->x && k < d->K) ? d->x_slot[k] : nullptr;
-        if (p.xs[k] && (!slot_align || ((uintptr_t)p.xs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.xs[k];
+        slot_bits |= (uintptr_t)p.xs[k] & 15;
     }
+    const void* slot_align = (const void*)(slot_bits | 16);   // synthetic address carrying that alignment (never dereferenced)
     if ((uint64_t)d->N * (uint64_t)d->x_sn * 4u >= (1ull << 32))
         return fail(KPGNN_ELIMIT, "aggregate_fwd: N * x row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->x_sn);
     const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
@@ -738,11 +727,12 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
     p.rowptr = d->rowptr_src; p.col = d->col_src; p.code = d->code_src; p.dis = d->dis;
     p.g = d->g; p.g_sn = d->g_sn; p.g_sk = d->g_sk; p.eps = d->eps;
     p.gx = d->gx; p.gx_sn = d->gx_sn; p.gx_sk = d->gx_sk; p.gtable0 = d->gtable0; p.gtablek = d->gtablek;
-    const void* slot_align = nullptr;
+    uintptr_t slot_bits = 0;            // (as in the forward: OR of the low address bits of all slot outputs)
     for (int k = 0; k < 16; ++k) {
         p.gxs[k] = (!d->gx && k < d->K) ? d->gx_slot[k] : nullptr;
-        if (p.gxs[k] && (!slot_align || ((uintptr_t)p.gxs[k] & 15) > ((uintptr_t)slot_align & 15))) slot_align = p.gxs[k];
+        slot_bits |= (uintptr_t)p.gxs[k] & 15;
     }
+    const void* slot_align = (const void*)(slot_bits | 16);
     p.acc_mask = d->gx ? 0u : d->accumulate_mask;
     // (the kernel requests the old value of an accumulating slot one hop ahead and stores a hop's result one hop late:
     //  two hops of one launch must not share a slot buffer)

@@ -45,7 +45,6 @@ struct CbParams {
     float* gv;
     float* slab;     // [gridDim.x][K][D] theta-gradient partials, or NULL
     int lds_ptab;    // floats of ptab staged in LDS (0: read from global)
-    int dbg;         // KPGNN_CB_DEBUG ablation bits (experiments only): 1 no uid / dictionary read
 };
 
 // Row streaming: a sub-group of G lanes owns one (node, hop) ROW of S per step and strides over the rows; the grid
@@ -102,7 +101,7 @@ combine_bwd_kernel(const CbParams p) {
                     else ldv<VEC>(p.gout + iu * p.go_sn + (int64_t)k * p.go_sk + c0, gvv[u]);
                     if (want_gt) {
                         if (p.periph) ldv<VEC>(p.periph + iu * p.p_sn + (int64_t)k * p.p_sk + c0, pv[u]);
-                        else if (p.uid && !(p.dbg & 1)) u_id[u] = p.uid[iu * p.uid_stride + k];
+                        else if (p.uid) u_id[u] = p.uid[iu * p.uid_stride + k];
                     }
                 }
             }
@@ -132,13 +131,13 @@ combine_bwd_kernel(const CbParams p) {
                 if (p.gv) stv<VEC>(p.gv + ru * D + c0, gvv[u]);
                 if (want_gt) {
                     if (u_id[u] >= 0) ldv<VEC>(ptp + (int64_t)u_id[u] * D + c0, pv[u]);
-                    if (!(p.dbg & 2)) for (int q = 0; q < VEC; ++q) gt[q] = fmaf(ghv[u][q], a[q] + pv[u][q], gt[q]);
+                    for (int q = 0; q < VEC; ++q) gt[q] = fmaf(ghv[u][q], a[q] + pv[u][q], gt[q]);
                 }
             }
             i += istep * UN;
         }
     }
-    if (!want_gt || (p.dbg & 4)) return;
+    if (!want_gt) return;
     // per-block theta-gradient partial: sub-groups of the block that met hop k2 are added in sub-group order
     if (col_ok) for (int q = 0; q < VEC; ++q) red[sg * D + c0 + q] = gt[q];
     __syncthreads();
@@ -240,7 +239,6 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     p.g = d->g; p.gv = d->gv; p.slab = nullptr;
     int grid = cb_grid(d->N, d->K, g, 8);           // upper bound (workspace check); the launcher picks the real one
     p.lds_ptab = 0;
-    { const char* e = getenv("KPGNN_CB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     if (d->gtheta) {
         const size_t need = sizeof(float) * (size_t)grid * d->K * d->D;
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= need, "combine_bwd: workspace too small (%zu < %zu)",

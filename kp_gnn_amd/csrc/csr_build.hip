@@ -221,49 +221,6 @@ tile_ptr_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ i
     tptr[t] = lo < A ? idx[lo] : idx[A - 1] + (tile_run_start(keys, A - 1) ? 1 : 0);   // (else: number of runs)
 }
 
-// ---------------------------------------------------------------------------------------------- component tiles
-__global__ void __launch_bounds__(kThreads)
-node_reach_kernel(const int32_t* __restrict__ rp_d, const int32_t* __restrict__ col_d, const int32_t* __restrict__ rp_s,
-                  const int32_t* __restrict__ col_s, int64_t N, int K, int32_t* __restrict__ hi) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    int32_t m = (int32_t)i;
-    for (int a = rp_d[i * K]; a < rp_d[(i + 1) * K]; ++a) m = max(m, col_d[a]);
-    for (int a = rp_s[i * K]; a < rp_s[(i + 1) * K]; ++a) m = max(m, col_s[a]);
-    hi[i] = m;
-}
-
-// hi[] already holds the inclusive prefix maximum.  One thread: greedy packing of components into tiles.
-__global__ void pack_tiles_kernel(const int32_t* __restrict__ pm, const int32_t* __restrict__ rp_d, int64_t N, int K,
-                                  int node_cap, int pair_cap, int32_t* __restrict__ tile_start,
-                                  uint8_t* __restrict__ tile_flag, int32_t* __restrict__ num_tiles) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int32_t nt = 0;
-    int64_t t0 = 0;        // start of the tile being filled
-    int64_t c0 = 0;        // start of the current component
-    for (int64_t i = 0; i < N; ++i) {
-        if (pm[i] > i) continue;                    // not a cut: component continues
-        const int64_t c1 = i + 1;                   // component [c0, c1)
-        const int64_t cn = c1 - c0;
-        const int64_t cp = (int64_t)rp_d[c1 * K] - rp_d[c0 * K];
-        if (cn > node_cap || cp > pair_cap) {       // oversize: close the open tile, chop into flagged chunks
-            if (c0 > t0) { tile_start[nt] = (int32_t)t0; tile_flag[nt] = 0; ++nt; }
-            for (int64_t s = c0; s < c1; s += node_cap) { tile_start[nt] = (int32_t)s; tile_flag[nt] = 1; ++nt; }
-            t0 = c1;
-        } else {
-            const int64_t tp = (int64_t)rp_d[c1 * K] - rp_d[t0 * K];
-            if (c1 - t0 > node_cap || tp > pair_cap) {   // does not fit the open tile: close it before c0
-                tile_start[nt] = (int32_t)t0; tile_flag[nt] = 0; ++nt;
-                t0 = c0;
-            }
-        }
-        c0 = c1;
-    }
-    if (N > t0) { tile_start[nt] = (int32_t)t0; tile_flag[nt] = 0; ++nt; }
-    tile_start[nt] = (int32_t)N;
-    num_tiles[0] = nt;
-}
-
 struct Workspace {
     int32_t* offs;
     uint32_t *keys_a, *keys_b;
@@ -430,45 +387,4 @@ extern "C" int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, con
         KPGNN_LAUNCH_CHECK("tile_ptr_kernel");
     }
     return KPGNN_OK;
-}
-
-
-extern "C" int kpgnn_csr_component_tiles(const int32_t* rowptr_dst, const int32_t* col_dst, const int32_t* rowptr_src,
-                                         const int32_t* col_src, int64_t N, int32_t K, int32_t node_cap,
-                                         int32_t pair_cap, int32_t* tile_start, uint8_t* tile_flag,
-                                         int32_t* num_tiles, void* workspace, size_t workspace_bytes,
-                                         kpgnn_stream_t stream) {
-    KPGNN_REQUIRE(N >= 0 && K >= 1 && node_cap >= 1 && pair_cap >= 1, "component_tiles: bad N=%lld K=%d caps=%d/%d",
-                  (long long)N, K, node_cap, pair_cap);
-    KPGNN_REQUIRE(rowptr_dst && rowptr_src && tile_start && tile_flag && num_tiles, "component_tiles: NULL pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (N == 0) {
-        KPGNN_HIP_TRY(hipMemsetAsync(tile_start, 0, sizeof(int32_t), s));
-        KPGNN_HIP_TRY(hipMemsetAsync(num_tiles, 0, sizeof(int32_t), s));
-        return KPGNN_OK;
-    }
-    size_t scan_bytes = 0;
-    KPGNN_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N,
-                                          rocprim::maximum<int32_t>()));
-    const size_t need = align_up(sizeof(int32_t) * (size_t)N) + align_up(scan_bytes ? scan_bytes : 1);
-    KPGNN_REQUIRE(workspace && workspace_bytes >= need, "component_tiles: workspace too small (%zu < %zu)", workspace_bytes, need);
-    int32_t* hi = (int32_t*)workspace;
-    void* tmp = (char*)workspace + align_up(sizeof(int32_t) * (size_t)N);
-    const unsigned blocks = (unsigned)((N + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(node_reach_kernel, dim3(blocks), dim3(kThreads), 0, s, rowptr_dst, col_dst, rowptr_src, col_src, N,
-                       (int)K, hi);
-    KPGNN_LAUNCH_CHECK("node_reach_kernel");
-    KPGNN_HIP_TRY(rocprim::inclusive_scan(tmp, scan_bytes, hi, hi, (size_t)N, rocprim::maximum<int32_t>(), s));
-    hipLaunchKernelGGL(pack_tiles_kernel, dim3(1), dim3(1), 0, s, hi, rowptr_dst, N, (int)K, (int)node_cap, (int)pair_cap,
-                       tile_start, tile_flag, num_tiles);
-    KPGNN_LAUNCH_CHECK("pack_tiles_kernel");
-    return KPGNN_OK;
-}
-
-extern "C" size_t kpgnn_csr_component_tiles_workspace_bytes(int64_t N) {
-    if (N <= 0) return 256;
-    size_t scan_bytes = 0;
-    if (rocprim::inclusive_scan(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)N,
-                                rocprim::maximum<int32_t>()) != hipSuccess) return 0;
-    return align_up(sizeof(int32_t) * (size_t)N) + align_up(scan_bytes ? scan_bytes : 1);
 }

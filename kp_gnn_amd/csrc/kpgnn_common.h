@@ -62,7 +62,6 @@ int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_
 // was done; otherwise kpgnn_table_grad falls back to its register-walk kernel.
 int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled);
 size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int U);
-int table_grad_bf16(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled);   // wide rows, exact bf16 x 3 split
 
 // erf(z) by Abramowitz-Stegun 7.1.26 (max abs error 5.4e-7 in fp32 over [-6,6]; exact +-1 beyond): ~14 VALU ops
 // against ~30 for libm's erff, which made the GELU epilogue VALU-bound (28 us of a 160 us launch).  Also

@@ -12,8 +12,6 @@
 // the next tile's loads are in flight while the current tile is walked, and the pair list is wave-uniform
 // (scalar loads).  Per-block partial tables go to a workspace slab with plain stores; a second launch adds
 // the slabs in block order (deterministic; only the few per-tile LDS flushes of the walker groups race).
-#include <cstdlib>
-
 #include "kpgnn_common.h"
 
 namespace kpgnn {
@@ -33,10 +31,7 @@ struct TgParams {
     const int32_t* uid; int64_t uid_stride;
     const float* theta;
     const float* gh;
-    float* slab;          // [gridDim.x][n0 + nk + U (+ K)][D]
-    // fused backward pre-pass (FUSE): g is COMPUTED here from S = pre, gh and theta and written out
-    const float* pre; const float* ptab; float* gout; int mode, want_gth;
-    int dbg;              // KPGNN_TG_DEBUG ablation bits (experiments only): 1 skip pair walk, 2 skip dictionary, 4 skip tile copy
+    float* slab;          // [gridDim.x][n0 + nk + U][D]
 };
 
 // g must be contiguous [N,K,D]: a tile of NT nodes is then one contiguous run of NT*K*D floats, copied to
@@ -44,11 +39,7 @@ struct TgParams {
 // The kGroups walker groups share the tile and the accumulator table; a group keeps the running sum of ITS
 // current code in a register and flushes it with an LDS atomic (a code can straddle two groups' chunks; the
 // flushes are a handful per tile, so the atomics cost nothing - unlike one atomic per edge).
-// FUSE: the tile of g is not loaded but computed: g[i,k,:] = theta[k,:]*gh[i,:]*act'(S[i,k,:]) (kpgnn_combine_bwd's
-// arithmetic), written to global memory for the gather kernel and kept in LDS for the walk; the theta gradient
-// sum_i gh*(act(S)+P) rides along as K extra accumulator rows.  One read of S and one write of g replace
-// combine_bwd's read+write plus table_grad's read.
-template <bool VEC4, bool FUSE>
+template <bool VEC4>
 __global__ void __launch_bounds__(kThreadsTG)
 table_grad_kernel(const TgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -59,8 +50,7 @@ table_grad_kernel(const TgParams p) {
     const bool col_ok = d < p.D;
     const int dc = col_ok ? d : 0;                   // clamped column for address arithmetic
     const int D = p.D;
-    const int Rt = p.n0 + p.nk + p.U;                // table rows; FUSE appends K theta-gradient rows
-    const int R = Rt + ((FUSE && p.want_gth) ? p.K : 0);
+    const int R = p.n0 + p.nk + p.U;                 // table rows
     const int tile_floats = p.NT * p.K * D;
     float* tile = lds;                               // [NT*K][D]
     float* acc = lds + ((tile_floats + 3) & ~3);     // [R][kCols], column-private
@@ -77,39 +67,7 @@ table_grad_kernel(const TgParams p) {
     for (int k = 0; k < 8; ++k) th[k] = (p.dict_src == 1 && k < p.K && col_ok) ? p.theta[k * D + d] : 0.f;
     constexpr int kPref = 4;
     float4 pref[kPref];
-    // FUSE mapping of the compute phase: 16 row lanes x 32 column lanes (16-B columns), rows rl, rl+16, ..
-    const int rl = threadIdx.x >> 5, cc = (threadIdx.x & 31) * 4;
-    const bool cok = cc < D;
-    const int rows = p.NT * p.K;
-    int fn[kPref], fk[kPref];                        // node-in-tile / hop of this thread's rows (tile independent)
-    float4 fth[kPref], fgh[kPref], facc[kPref];
-    int fu[kPref];
-    auto fuse_prefetch = [&](int64_t tl2) {
-        const int64_t node0 = tl2 * p.NT;
-#pragma unroll
-        for (int q = 0; q < kPref; ++q) {
-            const int r = rl + 16 * q;
-            pref[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            fgh[q] = pref[q];
-            fu[q] = -1;
-            if (r < rows && cok && node0 + fn[q] < p.N) {
-                pref[q] = *reinterpret_cast<const float4*>(p.pre + tl2 * tile_floats + (int64_t)r * D + cc);
-                fgh[q] = *reinterpret_cast<const float4*>(p.gh + (node0 + fn[q]) * D + cc);
-                if (p.want_gth && p.uid) fu[q] = p.uid[(node0 + fn[q]) * p.uid_stride + fk[q]];
-            }
-        }
-    };
-    if (FUSE) {
-#pragma unroll
-        for (int q = 0; q < kPref; ++q) {
-            const int r = rl + 16 * q;
-            fn[q] = r / p.K;
-            fk[q] = r - fn[q] * p.K;
-            facc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            fth[q] = (r < rows && cok) ? *reinterpret_cast<const float4*>(p.theta + fk[q] * D + cc) : facc[q];
-        }
-        if (blockIdx.x < num_tiles) fuse_prefetch(blockIdx.x);
-    } else if (VEC4) {
+    if (VEC4) {
 #pragma unroll
         for (int q = 0; q < kPref; ++q) {
             const int64_t i = (int64_t)blockIdx.x * tile_floats + (q * kThreadsTG + threadIdx.x) * 4;
@@ -174,46 +132,7 @@ table_grad_kernel(const TgParams p) {
         const int64_t base = tl * tile_floats;
         const int nfl = (int)min((int64_t)tile_floats, total - base);
         __syncthreads();                             // previous tile fully walked
-        if (FUSE) {
-            const int64_t node0 = tl * p.NT;
-#pragma unroll
-            for (int q = 0; q < kPref; ++q) {
-                const int r = rl + 16 * q;
-                if (r < rows && cok && node0 + fn[q] < p.N) {
-                    const float sv[4] = {pref[q].x, pref[q].y, pref[q].z, pref[q].w};
-                    const float gv[4] = {fth[q].x * fgh[q].x, fth[q].y * fgh[q].y, fth[q].z * fgh[q].z, fth[q].w * fgh[q].w};
-                    float gg[4], av[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (p.mode == KPGNN_MODE_GINPLUS) {
-                            float e2;
-                            const float cdf = 0.5f * (1.0f + fast_erf(sv[e] * 0.70710678118654752440f, &e2));
-                            av[e] = sv[e] * cdf;
-                            gg[e] = gv[e] * (cdf + sv[e] * e2 * 0.39894228040143267794f);
-                        } else if (p.mode == KPGNN_MODE_GCN) {
-                            av[e] = fmaxf(sv[e], 0.f);
-                            gg[e] = sv[e] > 0.f ? gv[e] : 0.f;
-                        } else {
-                            av[e] = sv[e];
-                            gg[e] = gv[e];
-                        }
-                    }
-                    const float4 g4 = make_float4(gg[0], gg[1], gg[2], gg[3]);
-                    *reinterpret_cast<float4*>(p.gout + base + (int64_t)r * D + cc) = g4;
-                    *reinterpret_cast<float4*>(tile + r * D + cc) = g4;
-                    if (p.want_gth) {
-                        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (fu[q] >= 0) pv = *reinterpret_cast<const float4*>(p.ptab + (int64_t)fu[q] * D + cc);
-                        facc[q].x = fmaf(fgh[q].x, av[0] + pv.x, facc[q].x); facc[q].y = fmaf(fgh[q].y, av[1] + pv.y, facc[q].y);
-                        facc[q].z = fmaf(fgh[q].z, av[2] + pv.z, facc[q].z); facc[q].w = fmaf(fgh[q].w, av[3] + pv.w, facc[q].w);
-                    }
-                } else if (r < rows && cok) {
-                    *reinterpret_cast<float4*>(tile + r * D + cc) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            if (tl + gridDim.x < num_tiles) fuse_prefetch(tl + gridDim.x);
-        } else if (p.dbg & 4) {
-        } else if (VEC4) {
+        if (VEC4) {
             // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
             for (int q = 0; q < kPref; ++q) {
@@ -241,7 +160,6 @@ table_grad_kernel(const TgParams p) {
         //      coalesced load (lane l holds entry l) and broadcasts them with v_readlane (SGPR, no LDS, no
         //      scalar-cache misses); the LDS tile reads of 8 entries are issued back to back before the
         //      (sequential, register-only) run accumulation.  The next chunk is fetched while this one is walked.
-        if (p.dbg & 1) end = beg;
         // every lane decodes ITS entry once (VALU, 64 entries per instruction); the per-entry scalar work is then three
         // v_readlane, one compare and the fma
         int vmul, voff, vrow;
@@ -283,7 +201,7 @@ table_grad_kernel(const TgParams p) {
         }
         // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register;
         //      theta / gh sit in registers, the (wave-uniform) uids of a node are fetched together
-        if (p.U > 0 && !(p.dbg & 2)) {
+        if (p.U > 0) {
             const int64_t node0 = tl * p.NT;
             for (int n = grp; n < p.NT && node0 + n < p.N; n += kGroups) {
                 const float ghv = ghs[n * kCols + t];
@@ -305,16 +223,6 @@ table_grad_kernel(const TgParams p) {
     }
     if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
     if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
-    if (FUSE && p.want_gth && cok) {                 // theta-gradient partials -> K extra accumulator rows
-#pragma unroll
-        for (int q = 0; q < kPref; ++q) {
-            if (rl + 16 * q < rows) {
-                float* dst = &acc[(Rt + fk[q]) * kCols + cc];
-                atomicAdd(dst + 0, facc[q].x); atomicAdd(dst + 1, facc[q].y);
-                atomicAdd(dst + 2, facc[q].z); atomicAdd(dst + 3, facc[q].w);
-            }
-        }
-    }
     __syncthreads();
     if (col_ok) {
         float* out = p.slab + (int64_t)blockIdx.x * R * D + d;
@@ -370,10 +278,10 @@ namespace {
 
 struct Plan { int grid_x, grid_y; size_t lds, ws_bytes; int R; };
 
-int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl, int extra_rows = 0) {
+int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     if (NT * K > kMaxRows || K > 8 || NT > 8)
         return fail(KPGNN_ELIMIT, "table_grad: nodes_per_tile=%d x K=%d exceeds the %d-row (8x8) register tile", NT, K, kMaxRows);
-    pl->R = n0 + nk + U + extra_rows;
+    pl->R = n0 + nk + U;
     pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)kCols * (pl->R + 8));
     if (pl->lds > 160 * 1024)
         return fail(KPGNN_ELIMIT, "table_grad: %zu B of LDS needed (tile %dx%d rows + %d table rows)", pl->lds, NT, K, pl->R);
@@ -399,8 +307,7 @@ extern "C" size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t
     Plan pl;
     if (N <= 0 || K < 1 || D < 1 || nodes_per_tile < 1) return 0;
     const size_t mfma = table_grad_mfma_ws_bytes(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict);
-    // (sized for the fused pre-pass as well: K extra theta-gradient rows)
-    if (make_plan(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict, &pl, K) != KPGNN_OK) return mfma;
+    if (make_plan(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict, &pl) != KPGNN_OK) return mfma;
     return pl.ws_bytes > mfma ? pl.ws_bytes : mfma;  // 0 means "neither kernel fits": the caller takes its atomic fallback
 }
 
@@ -409,38 +316,22 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->K <= 4096 && d->D >= 1 && d->nodes_per_tile >= 1 && d->nodes_per_tile <= 8,
                   "table_grad: bad N=%d K=%d D=%d nodes_per_tile=%d", d->N, d->K, d->D, d->nodes_per_tile);
     if (d->N == 0) return KPGNN_OK;
-    const bool fuse = d->fuse_pre != nullptr;
-    KPGNN_REQUIRE(fuse || d->g != nullptr, "table_grad: NULL g");
-    if (fuse) {
-        KPGNN_REQUIRE(d->fuse_g && d->theta && d->gh, "table_grad: fused pre-pass needs fuse_g, theta, gh");
-        KPGNN_REQUIRE(d->D % 4 == 0 && d->D <= 128 && d->K <= 8, "table_grad: fused pre-pass needs D %% 4 == 0, D <= 128, K <= 8");
-        KPGNN_REQUIRE(!d->gtheta || !d->uid || d->fuse_ptab, "table_grad: theta gradient with a dictionary P needs fuse_ptab");
-    }
+    KPGNN_REQUIRE(d->g != nullptr, "table_grad: NULL g");
     const bool edges = d->tile_ptr != nullptr;
     KPGNN_REQUIRE(!edges || (d->gtable0 && d->n_code0 >= 1 && (d->K == 1 || (d->gtablek && d->n_codek >= 1))),
                   "table_grad: missing gtable0/gtablek");
     KPGNN_REQUIRE(d->n_dict >= 0 && (d->n_dict == 0 || (d->uid && d->gdict && d->uid_stride >= d->K &&
                   (d->dict_src == 2 || (d->dict_src == 1 && d->theta && d->gh)))),
                   "table_grad: dictionary gradient needs uid/gdict and (theta, gh) or dict_src 2");
-    KPGNN_REQUIRE(edges || d->n_dict > 0 || fuse, "table_grad: nothing to do");
+    KPGNN_REQUIRE(edges || d->n_dict > 0, "table_grad: nothing to do");
     hipStream_t s = (hipStream_t)stream;
-    KPGNN_REQUIRE(fuse || (d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D), "table_grad: g must be contiguous [N,K,D]");
+    KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
         // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
         // dictionary rows) at D = 13.  Wide rows stay on the register walk (D = 104: 78 vs 121 us; the 16x16x4 product
-        // is matrix-core bound there).  KPGNN_TG_KERNEL=walk|mfma|bf16 forces one of them.
-        const char* fe = getenv("KPGNN_TG_KERNEL");          // read per call: the parity tests flip it
-        const int force = !fe ? 0 : (fe[0] == 'w' ? 1 : (fe[0] == 'm' ? 2 : (fe[0] == 'b' ? 3 : 0)));
+        // is matrix-core bound there).  d->kernel = 1 / 2 forces one of them (the parity tests compare the two).
+        const int force = d->kernel;
         const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows;
-        // wide rows, opt-in (KPGNN_TG_KERNEL=bf16): count matrix x (g split exactly into three bf16 parts) on the bf16
-        // matrix cores, when the caller vouches that no segment holds more than 256 pairs (counts stay exact in bf16).
-        // Measured 112 us against the walk's 105 us over the bench's k = 1..8 mix (85 vs 98 us at k = 8 with unsorted
-        // dictionary ids): the three-part product is matrix-core bound and its phases do not overlap the g stream.
-        if (force == 3 && d->D > 32 && d->max_pairs_per_segment >= 1 && d->max_pairs_per_segment <= 256) {
-            bool handled = false;
-            const int rc = table_grad_bf16(d, s, &handled);
-            if (rc != KPGNN_OK || handled) return rc;
-        }
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
@@ -451,32 +342,23 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
     p.n0 = edges ? d->n_code0 : 0; p.nk = (edges && d->K > 1) ? d->n_codek : 0;
     p.U = d->n_dict; p.dict_src = d->dict_src;
-    p.pre = d->fuse_pre; p.ptab = d->fuse_ptab; p.gout = d->fuse_g; p.mode = d->fuse_mode; p.want_gth = (fuse && d->gtheta) ? 1 : 0;
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
-    { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     Plan pl;
-    int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl, p.want_gth ? p.K : 0);
+    int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl);
     if (rc != KPGNN_OK) return rc;
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     p.slab = (float*)d->workspace;
     // the tile copy is flat: 16-B loads only need every node's K*D floats to be a multiple of 4
     const bool vec4 = (((int64_t)p.K * p.D) % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
-    if (fuse) {
-        KPGNN_REQUIRE((((uintptr_t)p.pre | (uintptr_t)p.gout | (uintptr_t)p.gh | (uintptr_t)p.theta | (uintptr_t)p.ptab) & 15) == 0,
-                      "table_grad: fused pre-pass operands must be 16-B aligned");
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<true, true>, pl.lds));
-        hipLaunchKernelGGL((table_grad_kernel<true, true>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
-    } else {
-        if (pl.lds > 64 * 1024) {
-            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<true, false>, pl.lds));
-            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<false, false>, pl.lds));
-        }
-        if (vec4) hipLaunchKernelGGL((table_grad_kernel<true, false>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
-        else hipLaunchKernelGGL((table_grad_kernel<false, false>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
+    if (pl.lds > 64 * 1024) {
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<true>, pl.lds));
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<false>, pl.lds));
     }
+    if (vec4) hipLaunchKernelGGL((table_grad_kernel<true>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
+    else hipLaunchKernelGGL((table_grad_kernel<false>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
     KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
-                       (int64_t)p.nk * p.D, d->gdict, s, (int64_t)p.U * p.D, p.want_gth ? d->gtheta : nullptr);
+                       (int64_t)p.nk * p.D, d->gdict, s);
 }

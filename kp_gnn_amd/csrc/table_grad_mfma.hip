@@ -36,7 +36,6 @@ struct TgmParams {
     const float* theta;
     const float* gh;
     float* slab;              // [gridDim.x * KQ][R][D]
-    int dbg;                  // KPGNN_TG_DEBUG ablation bits (experiments only): 1 no MFMA phase, 2 no count matrix, 4 no tile copy
 };
 
 template <int MAXIT, int MTMAX>
@@ -125,8 +124,7 @@ table_grad_mfma_kernel(const TgmParams p) {
         const int beg = nbeg, end = nend, myu = nu;
         const uint32_t myw = nw;
         __syncthreads();                             // previous tile: MFMA reads and cell resets are done
-        if (p.dbg & 4) {
-        } else if (p.vec4) {
+        if (p.vec4) {
 #pragma unroll
             for (int q = 0; q < kTgmPF; ++q) {
                 const int i = 4 * (tid + q * kTgmThreads);
@@ -141,7 +139,7 @@ table_grad_mfma_kernel(const TgmParams p) {
             for (int i = tid; i < tile_floats; i += kTgmThreads) tile[i] = (base + i < total) ? p.g[base + i] : 0.f;
         }
         // count matrix of this tile
-        if (!(p.dbg & 2)) {
+        {
             const int c = cell_of(myw);
             if (c >= 0) atomicAdd(&cnt[c], mult_of(myw));
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
@@ -164,7 +162,7 @@ table_grad_mfma_kernel(const TgmParams p) {
             if (nx < num_tiles) { issue_tile(nx); issue_meta(nx); }
         }
         // C x g_tile
-        if (wave < nitems && !(p.dbg & 1)) {
+        if (wave < nitems) {
             int n_idx = n_start, k_idx = k_start;
             for (int q = q0; q < q1; ++q) {
                 const int row = 4 * q + lq;
@@ -200,7 +198,7 @@ table_grad_mfma_kernel(const TgmParams p) {
         }
         __syncthreads();
         // reset the touched cells (cheaper than clearing Rp x CP words per tile)
-        if (!(p.dbg & 2)) {
+        {
             const int c = cell_of(myw);
             if (c >= 0) cnt[c] = 0;
             for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
@@ -233,305 +231,6 @@ table_grad_mfma_kernel(const TgmParams p) {
             }
         }
     }
-}
-
-// ----------------------------------------------------------------------------------------- wide rows: bf16 x 3
-// The count matrix holds small integers - exact in bf16 - and every fp32 value of the g tile splits EXACTLY into three
-// bf16 parts by truncation (x = hi + mid + lo: 8 + 8 + 8 mantissa bits), so  C x g = C x hi + C x mid + C x lo  runs on
-// v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate) with fp32 accumulation and no rounding beyond the accumulate
-// itself: every bf16 x bf16 product is exact in fp32.  Counts above 256 are not exact in bf16: the host only picks
-// this kernel when no (node, hop) segment is longer than 256 pairs.
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-union Frag { bf16x8 v; uint32_t u[4]; };
-
-__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(hi);
-    mid = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mid);
-    lo = __float_as_uint(r2) & 0xFFFF0000u;
-}
-
-struct TgbParams {
-    int N, K, D, NT, n0, U, dict_src;
-    int RE, REp, Rp, R, MT, MTE, rows, QS16, CP, NT32, KQ, vec4;
-    const int32_t* tptr;
-    const uint32_t* tpack;
-    const float* g;
-    const int32_t* uid; int64_t uid_stride;
-    const float* theta;
-    const float* gh;
-    float* slab;              // [gridDim.x * KQ][R][D]
-    int dbg;                  // KPGNN_TG_DEBUG ablation bits (experiments only): 1 no MFMA phase, 2 no count matrix, 4 no tile copy
-};
-
-template <int MAXIT, int MTMAX>
-__global__ void __launch_bounds__(kTgmThreads, 2)
-table_grad_bf16_kernel(const TgbParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = p.D, K = p.K, rows = p.rows, CP = p.CP, QS = p.QS16;
-    const int tile_floats = rows * D;
-    const int tile_alloc = (16 * QS * D + 3) & ~3;           // rows padded to the 16-row k-step with zeros
-    float* tile = lds;
-    float* cnt = tile + tile_alloc;                           // [Rp][CP] counts as exact small floats
-    float* thl = cnt + p.Rp * CP;                             // [K][D]   (dict_src 1)
-    float* ghs = thl + K * D;                                 // [NT][D]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lc = lane & 31, lh = lane >> 5;
-    const bool dsrc1 = p.U > 0 && p.dict_src == 1;
-
-    for (int i = tid; i < tile_alloc; i += kTgmThreads) tile[i] = 0.f;
-    for (int i = tid; i < p.Rp * CP; i += kTgmThreads) cnt[i] = 0.f;
-    if (dsrc1)
-        for (int i = tid; i < K * D; i += kTgmThreads) thl[i] = p.theta[i];
-
-    const int nitems = p.NT32 * p.KQ;
-    int nt_of[MAXIT];
-    bool it_on[MAXIT];
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) {
-        const int it = wave + j * kTgmWaves;
-        it_on[j] = it < nitems;
-        nt_of[j] = it_on[j] ? it / p.KQ : 0;
-    }
-    const int kq = (wave < nitems) ? wave % p.KQ : 0;
-    const int q0 = kq * QS / p.KQ, q1 = (kq + 1) * QS / p.KQ;
-
-    f32x16 acc[MAXIT][MTMAX];
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j)
-#pragma unroll
-        for (int m = 0; m < MTMAX; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][m][e] = 0.f;
-
-    const int64_t num_tiles = ((int64_t)p.N + p.NT - 1) / p.NT;
-    const int64_t total = (int64_t)p.N * K * D;
-    // a block owns a CONTIGUOUS range of tiles
-    const int64_t per = (num_tiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * per;
-    const int64_t t1 = t0 + per < num_tiles ? t0 + per : num_tiles;
-    float4 pf[kTgmPF];
-    auto issue_tile = [&](int64_t tl) {
-        if (!p.vec4) return;
-        const int64_t base = tl * tile_floats;
-#pragma unroll
-        for (int q = 0; q < kTgmPF; ++q) {
-            const int i = 4 * (tid + q * kTgmThreads);
-            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < tile_floats && base + i < total) pf[q] = *reinterpret_cast<const float4*>(p.g + base + i);
-        }
-    };
-    int nbeg = 0, nend = 0, nu = -1;
-    uint32_t nw = 0xFFFFFFFFu;
-    auto issue_meta = [&](int64_t tl) {
-        nbeg = nend = 0; nw = 0xFFFFFFFFu; nu = -1;
-        if (p.tptr) {
-            nbeg = p.tptr[tl]; nend = p.tptr[tl + 1];
-            if (nbeg + tid < nend) nw = p.tpack[nbeg + tid];
-        }
-        if (p.U > 0 && tid < rows) {
-            const int n = tid / K;
-            const int64_t node = tl * p.NT + n;
-            if (node < p.N) nu = p.uid[node * p.uid_stride + (tid - n * K)];
-        }
-    };
-    if (t0 < t1) { issue_tile(t0); issue_meta(t0); }
-    auto cell_of = [&](uint32_t w) -> int {
-        const int hop = (int)(w & 0x3F);
-        if (hop >= K) return -1;
-        const int nit = (int)((w >> 12) & 7);
-        const int cc = (int)(w >> 15);
-        const int r = (cc >> 16) ? p.n0 + (cc & 0xFFFF) : cc;
-        if (r >= p.RE) return -1;
-        return r * CP + nit * K + hop;
-    };
-
-    for (int64_t tl = t0; tl < t1; ++tl) {
-        const int64_t base = tl * tile_floats;
-        const int beg = nbeg, end = nend, myu = nu;
-        const uint32_t myw = nw;
-        __syncthreads();
-        if (p.dbg & 4) {
-        } else if (p.vec4) {
-#pragma unroll
-            for (int q = 0; q < kTgmPF; ++q) {
-                const int i = 4 * (tid + q * kTgmThreads);
-                if (i < tile_floats) *reinterpret_cast<float4*>(tile + i) = pf[q];
-            }
-            for (int i = 4 * (tid + kTgmPF * kTgmThreads); i < tile_floats; i += 4 * kTgmThreads) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (base + i < total) v = *reinterpret_cast<const float4*>(p.g + base + i);
-                *reinterpret_cast<float4*>(tile + i) = v;
-            }
-        } else {
-            for (int i = tid; i < tile_floats; i += kTgmThreads) tile[i] = (base + i < total) ? p.g[base + i] : 0.f;
-        }
-        if (!(p.dbg & 2)) {
-            const int c = cell_of(myw);
-            if (c >= 0) atomicAdd(&cnt[c], (float)mult_of(myw));
-            for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
-                const uint32_t w2 = p.tpack[e];
-                const int c2 = cell_of(w2);
-                if (c2 >= 0) atomicAdd(&cnt[c2], (float)mult_of(w2));
-            }
-            if ((unsigned)myu < (unsigned)p.U) cnt[(p.REp + myu) * CP + tid] = 1.0f;
-        }
-        if (dsrc1) {
-            const int64_t node0 = tl * p.NT;
-            for (int i = tid; i < p.NT * D; i += kTgmThreads) {
-                const int n = i / D;
-                ghs[i] = (node0 + n < p.N) ? p.gh[node0 * D + i] : 0.f;
-            }
-        }
-        __syncthreads();
-        {
-            const int64_t nx = tl + 1;
-            if (nx < t1) { issue_tile(nx); issue_meta(nx); }
-        }
-        if (wave < nitems && !(p.dbg & 1)) {
-            for (int q = q0; q < q1; ++q) {
-                const int rowbase = 16 * q + 8 * lh;
-                Frag bh[MAXIT], bm[MAXIT], bl[MAXIT], dh[MAXIT], dm[MAXIT], dl[MAXIT];
-#pragma unroll
-                for (int j = 0; j < MAXIT; ++j) {
-                    if (!it_on[j]) continue;
-                    const int col = nt_of[j] * 32 + lc;
-                    const int cc = col < D ? col : D - 1;
-                    const bool cok = col < D;
-                    int n_idx = rowbase / K, k_idx = rowbase - n_idx * K;
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) {
-                        uint32_t h0, m0, l0, h1, m1, l1;
-                        const float x0 = cok ? tile[(rowbase + 2 * e2) * D + cc] : 0.f;
-                        const float x1 = cok ? tile[(rowbase + 2 * e2 + 1) * D + cc] : 0.f;
-                        split3(x0, h0, m0, l0);
-                        split3(x1, h1, m1, l1);
-                        bh[j].u[e2] = (h0 >> 16) | h1; bm[j].u[e2] = (m0 >> 16) | m1; bl[j].u[e2] = (l0 >> 16) | l1;
-                        if (dsrc1) {
-                            float y[2];
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                const bool ok = cok && n_idx < p.NT;
-                                const int nn = n_idx < p.NT ? n_idx : p.NT - 1;
-                                y[t] = ok ? thl[k_idx * D + cc] * ghs[nn * D + cc] : 0.f;
-                                if (++k_idx == K) { k_idx = 0; ++n_idx; }
-                            }
-                            split3(y[0], h0, m0, l0);
-                            split3(y[1], h1, m1, l1);
-                            dh[j].u[e2] = (h0 >> 16) | h1; dm[j].u[e2] = (m0 >> 16) | m1; dl[j].u[e2] = (l0 >> 16) | l1;
-                        }
-                    }
-                }
-                Frag a[MTMAX];
-#pragma unroll
-                for (int m = 0; m < MTMAX; ++m) {
-                    if (m < p.MT) {
-                        const float* cr = cnt + (m * 32 + lc) * CP + rowbase;
-                        const float4 c0 = *reinterpret_cast<const float4*>(cr);
-                        const float4 c1 = *reinterpret_cast<const float4*>(cr + 4);
-                        a[m].u[0] = (__float_as_uint(c0.x) >> 16) | (__float_as_uint(c0.y) & 0xFFFF0000u);
-                        a[m].u[1] = (__float_as_uint(c0.z) >> 16) | (__float_as_uint(c0.w) & 0xFFFF0000u);
-                        a[m].u[2] = (__float_as_uint(c1.x) >> 16) | (__float_as_uint(c1.y) & 0xFFFF0000u);
-                        a[m].u[3] = (__float_as_uint(c1.z) >> 16) | (__float_as_uint(c1.w) & 0xFFFF0000u);
-                    }
-                }
-                // parts outermost: consecutive MFMAs hit different accumulators (no back-to-back dependence)
-#pragma unroll
-                for (int part = 0; part < 3; ++part) {
-#pragma unroll
-                    for (int j = 0; j < MAXIT; ++j) {
-                        if (!it_on[j]) continue;
-#pragma unroll
-                        for (int m = 0; m < MTMAX; ++m) {
-                            if (m < p.MT) {
-                                const bool dict_tile = dsrc1 && m >= p.MTE;
-                                const bf16x8 bsel = part == 0 ? (dict_tile ? dh[j].v : bh[j].v)
-                                                  : (part == 1 ? (dict_tile ? dm[j].v : bm[j].v) : (dict_tile ? dl[j].v : bl[j].v));
-                                acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m].v, bsel, acc[j][m], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (!(p.dbg & 2)) {
-            const int c = cell_of(myw);
-            if (c >= 0) cnt[c] = 0.f;
-            for (int e = beg + tid + kTgmThreads; e < end; e += kTgmThreads) {
-                const int c2 = cell_of(p.tpack[e]);
-                if (c2 >= 0) cnt[c2] = 0.f;
-            }
-            if ((unsigned)myu < (unsigned)p.U) cnt[(p.REp + myu) * CP + tid] = 0.f;
-        }
-    }
-    if (wave < nitems) {
-        float* out = p.slab + ((int64_t)blockIdx.x * p.KQ + kq) * ((int64_t)p.R * D);
-#pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            if (!it_on[j]) continue;
-            const int col = nt_of[j] * 32 + lc;
-            if (col >= D) continue;
-#pragma unroll
-            for (int m = 0; m < MTMAX; ++m) {
-                if (m < p.MT) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rr = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        int orow = -1;
-                        if (rr < p.RE) orow = rr;
-                        else if (rr >= p.REp && rr - p.REp < p.U) orow = p.RE + (rr - p.REp);
-                        if (orow >= 0) out[(int64_t)orow * D + col] = acc[j][m][e];
-                    }
-                }
-            }
-        }
-    }
-}
-
-struct TgbPlan { int rows, QS16, CP, RE, REp, Rp, R, MT, MTE, NT32, KQ, maxit, mtmax, grid; size_t lds, ws_bytes; };
-
-bool tgb_plan(int N, int K, int D, int NT, int n0, int nk, int U, bool dsrc1, TgbPlan* pl) {
-    if (N < 1 || K < 1 || D < 33 || D > 256 || NT < 1 || NT > 8) return false;
-    pl->rows = NT * K;
-    if (pl->rows > 128) return false;
-    pl->QS16 = (pl->rows + 15) / 16;
-    const int cp = 16 * pl->QS16;
-    pl->CP = cp + 4;                                     // rows 16-B aligned, 4 words of skew between rows
-    pl->RE = n0 + nk;
-    pl->REp = (pl->RE + 31) & ~31;
-    pl->Rp = pl->REp + ((U + 31) & ~31);
-    pl->R = pl->RE + U;
-    if (pl->Rp < 32 || pl->Rp > 256) return false;
-    pl->MT = pl->Rp / 32;
-    pl->MTE = pl->REp / 32;
-    pl->NT32 = (D + 31) / 32;
-    int kq = pl->NT32 >= 4 ? 1 : (pl->NT32 == 2 ? 2 : 1);
-    if (kq > pl->QS16) kq = pl->QS16;
-    pl->KQ = kq;
-    const int per_wave = (pl->NT32 * kq + kTgmWaves - 1) / kTgmWaves;
-    if (per_wave > 2) return false;
-    pl->maxit = per_wave;
-    pl->mtmax = pl->MT <= 2 ? 2 : (pl->MT <= 4 ? 4 : 8);
-    if (pl->maxit * pl->mtmax > 8) return false;
-    const size_t tile_alloc = ((size_t)16 * pl->QS16 * D + 3) & ~(size_t)3;
-    const int64_t tiles = ((int64_t)N + NT - 1) / NT;
-    const size_t cap = (size_t)device_facts().lds_per_block;
-    const size_t fixed = sizeof(float) * (tile_alloc + (size_t)pl->Rp * pl->CP + (size_t)(K + NT) * D);
-    if (fixed + 64 > cap) return false;
-    int per_cu = (int)(cap / (fixed + 256));
-    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    int64_t g = (int64_t)device_facts().cu_count * per_cu;
-    if (g > tiles) g = tiles;
-    if (g < 1) g = 1;
-    const int64_t per = (tiles + g - 1) / g;                  // tiles per block (its row-pointer window lives in LDS)
-    pl->lds = fixed + sizeof(int) * (size_t)(per + 1);
-    if (pl->lds > cap) return false;
-    pl->grid = (int)g;
-    pl->ws_bytes = sizeof(float) * (size_t)pl->grid * kq * (size_t)pl->R * D;
-    (void)dsrc1;
-    return true;
 }
 
 struct TgmPlan { int rows, QS, CP, RE, REp, Rp, R, MT, MTE, NTILES, KQ, maxit, mtmax, grid; size_t lds, ws_bytes; };
@@ -578,50 +277,15 @@ bool tgm_plan(int N, int K, int D, int NT, int n0, int nk, int U, bool dsrc1, Tg
 
 size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int U) {
     TgmPlan pl;
-    TgbPlan pb;
-    size_t a = 0, b = 0;
-    for (int ds = 0; ds < 2; ++ds) {       // (the LDS footprint, hence the grid, depends on the dictionary source)
+    size_t a = 0;
+    for (int ds = 0; ds < 2; ++ds)         // (the LDS footprint, hence the grid, depends on the dictionary source)
         if (tgm_plan(N, K, D, NT, n0, nk, U, ds != 0, &pl) && pl.ws_bytes > a) a = pl.ws_bytes;
-        if (tgb_plan(N, K, D, NT, n0, nk, U, ds != 0, &pb) && pb.ws_bytes > b) b = pb.ws_bytes;
-    }
-    return a > b ? a : b;
-}
-
-// Wide rows on the bf16 matrix cores (exact 3-way split).  max_pairs_per_segment <= 256 is the caller's promise.
-int table_grad_bf16(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled) {
-    *handled = false;
-    if (d->fuse_pre != nullptr) return KPGNN_OK;
-    const bool edges = d->tile_ptr != nullptr;
-    const int n0 = edges ? d->n_code0 : 0, nk = (edges && d->K > 1) ? d->n_codek : 0;
-    const bool dsrc1 = d->n_dict > 0 && d->dict_src == 1;
-    TgbPlan pl;
-    if (!tgb_plan(d->N, d->K, d->D, d->nodes_per_tile, n0, nk, d->n_dict, dsrc1, &pl)) return KPGNN_OK;
-    if (!d->workspace || d->workspace_bytes < pl.ws_bytes) return KPGNN_OK;
-    TgbParams p;
-    p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile; p.n0 = n0; p.U = d->n_dict; p.dict_src = d->dict_src;
-    p.RE = pl.RE; p.REp = pl.REp; p.Rp = pl.Rp; p.R = pl.R; p.MT = pl.MT; p.MTE = pl.MTE; p.rows = pl.rows; p.QS16 = pl.QS16;
-    p.CP = pl.CP; p.NT32 = pl.NT32; p.KQ = pl.KQ;
-    p.vec4 = (((int64_t)d->K * d->D) % 4 == 0) && ((((uintptr_t)d->g) & 15) == 0);
-    p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
-    p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
-    p.slab = (float*)d->workspace;
-    { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-#define KP_TGB(IT, MTV) do { \
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_bf16_kernel<IT, MTV>, pl.lds)); \
-        hipLaunchKernelGGL((table_grad_bf16_kernel<IT, MTV>), dim3(pl.grid), dim3(kTgmThreads), pl.lds, s, p); } while (0)
-    if (pl.maxit == 1) { if (pl.mtmax == 2) KP_TGB(1, 2); else if (pl.mtmax == 4) KP_TGB(1, 4); else KP_TGB(1, 8); }
-    else { if (pl.mtmax == 2) KP_TGB(2, 2); else KP_TGB(2, 4); }
-#undef KP_TGB
-    KPGNN_LAUNCH_CHECK("table_grad_bf16_kernel");
-    *handled = true;
-    return slab_reduce(p.slab, pl.grid * pl.KQ, (int64_t)pl.R * p.D, d->gtable0, (int64_t)n0 * p.D, d->gtablek,
-                       (int64_t)nk * p.D, d->gdict, s);
+    return a;
 }
 
 // Returns KPGNN_OK with *handled = true when the launch was done here; *handled = false leaves it to the walk kernel.
 int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled) {
     *handled = false;
-    if (d->fuse_pre != nullptr) return KPGNN_OK;
     const bool edges = d->tile_ptr != nullptr;
     const int n0 = edges ? d->n_code0 : 0, nk = (edges && d->K > 1) ? d->n_codek : 0;
     const bool dsrc1 = d->n_dict > 0 && d->dict_src == 1;
@@ -636,7 +300,6 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
     p.slab = (float*)d->workspace;
-    { const char* e = getenv("KPGNN_TG_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     // one resident round: the plan sizes the grid by LDS alone, the registers (accumulators of all row tiles) usually
     // allow fewer blocks per CU - a smaller grid also means a smaller slab to write and reduce
     int grid = pl.grid;

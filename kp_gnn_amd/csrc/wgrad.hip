@@ -117,7 +117,7 @@ namespace kpgnn {
 namespace {
 
 struct LinParams {
-    int64_t N; int O, I, pitch, ypitch, wt, dbg;
+    int64_t N; int O, I, pitch, ypitch, wt;
     const float* x; int64_t xs;
     const float* w; const float* bias;
     float* y; int64_t ys;
@@ -206,7 +206,6 @@ linear_fwd_kernel(const LinParams p) {
         const float* b0 = xl + c * pitch + kk;
         // I == 2 * KS exactly (host): plain LDS reads the scheduler can hoist ahead of the MFMAs (a per-lane predicate
         // on the read made every MFMA wait for its own ds_read: 31 us instead of ~13)
-        if (!(p.dbg & 1))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -215,26 +214,8 @@ linear_fwd_kernel(const LinParams p) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xv, acc[m], 0, 0, 0);
             }
         }
-        if (p.dbg & 4) {                               // experiment: results straight from the accumulators (64 x 16-B segments per store)
-            const int64_t r0 = tile * ROWS;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ob = wave * 32 + 8 * g + 4 * kk;
-                if (ob < O) {
-                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + ob);
-#pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        const int64_t r = r0 + m * 32 + c;
-                        if (r < p.N)
-                            *reinterpret_cast<float4*>(p.y + r * p.ys + ob) =
-                                make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
-                    }
-                }
-            }
-        }
         __syncthreads();                               // every wave is done reading the x tile: it becomes the y tile
-        if (!(p.dbg & 6)) {
+        {
         // C/D map: col = lane & 31 (tile row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -364,7 +345,6 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
         return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
     LinParams p;
     p.N = d->N; p.O = d->O; p.I = d->I; p.wt = d->w_transposed ? 1 : 0;
-    { const char* e = getenv("KPGNN_LIN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     // one pitch = 4 (mod 8) floats for the x and the y view of the buffer: 16-B aligned rows (the tile is committed and
     // drained with b128 LDS accesses); the transposed operand reads then see a 2-way bank conflict, which hides behind
     // the 64-cycle MFMAs
@@ -377,12 +357,10 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const int64_t slots = (int64_t)device_facts().cu_count * 2;
     int m = (int)((d->N + slots * 32 - 1) / (slots * 32));
     m = m < 1 ? 1 : (m > 3 ? 3 : m);
-    { const char* e = getenv("KPGNN_LIN_M"); if (e && atoi(e) >= 1 && atoi(e) <= 3) m = atoi(e); }
     const int rows = 32 * m;
     const size_t lds = sizeof(float) * (size_t)rows * rowp;
     const int64_t tiles = (d->N + rows - 1) / rows;
     int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
-    { const char* e = getenv("KPGNN_LIN_GRID"); if (e && atoi(e) >= 1 && atoi(e) < grid) grid = atoi(e); }
     hipStream_t s = (hipStream_t)stream;
     dim3 blk(256);
     const int ks = (d->I + 1) / 2;

@@ -22,7 +22,7 @@ class KHopCSR:
     """int32 CSR by (dst,hop) and by (src,hop) of the active (edge,hop) pairs."""
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
-                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "max_seg_pairs", "_dis", "_apairs", "_ctiles",
+                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
                  "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
@@ -30,29 +30,6 @@ class KHopCSR:
     def __init__(self):
         self._dis = None
         self._apairs = {}
-        self._ctiles = {}
-
-    def component_tiles(self, node_cap, pair_cap):
-        """Component-aligned node tiles (kpgnn_csr_component_tiles) for the LDS-staged kernels, cached per
-        (node_cap, pair_cap).  Returns (tile_start int32[T+1], tile_flag uint8[T], T); one host sync per build."""
-        key = (int(node_cap), int(pair_cap))
-        if key not in self._ctiles:
-            lib = _lib.load()
-            dev = self.device
-            ts = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
-            tf = torch.empty(max(self.N, 1), dtype=torch.uint8, device=dev)
-            nt = torch.zeros(1, dtype=torch.int32, device=dev)
-            nb = lib.kpgnn_csr_component_tiles_workspace_bytes(self.N)
-            ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.kpgnn_csr_component_tiles(
-                    self.rowptr_dst.data_ptr(), self.col_dst.data_ptr(), self.rowptr_src.data_ptr(),
-                    self.col_src.data_ptr(), self.N, self.K, key[0], key[1], ts.data_ptr(), tf.data_ptr(),
-                    nt.data_ptr(), ws.data_ptr(), ctypes.c_size_t(ws.numel()),
-                    torch.cuda.current_stream(dev).cuda_stream), "kpgnn_csr_component_tiles")
-            T = int(nt.item())
-            self._ctiles[key] = (ts[:T + 1].contiguous(), tf[:max(T, 1)].contiguous(), T)
-        return self._ctiles[key]
 
     def active_pairs(self, k_active):
         """Number of active (edge,hop) pairs within the first k_active hops (== A for k_active == K).
@@ -124,8 +101,6 @@ class KHopCSR:
                                            c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr(),
                                            c.nodes_per_tile, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(),
                                            ws.data_ptr(), ctypes.c_size_t(ws.numel()), stream), "kpgnn_csr_build")
-            # longest (node, hop) segment: the bf16 table-gradient kernel needs pair counts <= 256 (exact in bf16)
-            c.max_seg_pairs = int((c.rowptr_dst[1:] - c.rowptr_dst[:-1]).max()) if S > 0 else 0
         return c
 
 

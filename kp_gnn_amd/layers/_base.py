@@ -1,9 +1,8 @@
 """Shared plumbing of the K-hop conv layers (not part of the reference's surface)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
 from ..khop_csr import get_khop_csr, path_encoding_is_zero
+from ..ops import embedding_rows
 
 try:  # the reference's layers subclass PyG's MessagePassing (layers/KPGIN.py:12); keep that when PyG exists
     from torch_geometric.nn import MessagePassing as _PyGMessagePassing
@@ -58,5 +57,7 @@ class EdgeCodeTables(object):
             return x, None
         if isinstance(x, list) or path_encoding_is_zero(pe_attr):  # (lists only arrive with all-padding pe_attr)
             return x, self.hopk_node_path_emb.weight[0].detach()
-        pe = F.embedding(pe_attr, self.hopk_node_path_emb.weight, padding_idx=0)
+        # (non-zero path codes never come out of the reference's own pre-transform, Q1; the lookup goes through the
+        #  gather-sum kernels so that this path stays hipGraph-capturable - torch's embedding backward is not)
+        pe = embedding_rows(self.hopk_node_path_emb.weight, pe_attr, padding_idx=0)
         return torch.cat([x[:, :1], x[:, 1:] + pe], dim=1), None

@@ -1,8 +1,6 @@
 """Autograd operators over the C ABI (include/kpgnn.h).  Host-side plumbing only: tensors in, pointers
 and strides out; every arithmetic step of the K-hop aggregation runs in the HIP kernels."""
-import contextlib
 import ctypes
-import os as _os
 
 import torch
 
@@ -40,30 +38,6 @@ class LaunchTimer:
 
 
 _timer = None
-# Fused backward pre-pass (g, theta grad, table grads, dictionary grads in ONE launch of table_grad_kernel) is opt-in:
-# the 512-thread tile kernel does the erf arithmetic at lower occupancy than the streaming combine_bwd kernel and the
-# step came out 2 % slower (8.89 vs 8.69 ms at B = 2048).  KPGNN_FUSED_BWD=1 enables it; both paths are parity-tested.
-# measured (B=2048, hipGraph replay): forking table_grad onto a side stream is SLOWER (KP-GIN+ 8.92 vs 8.37 ms,
-# KP-GIN 5.33 vs 4.90 ms per step): the two kernels contend for the same CUs and the fork/join adds graph edges.
-_overlap_bwd = _os.environ.get("KPGNN_OVERLAP_BWD", "0") == "1"
-_side_streams = {}
-
-
-def _side_stream(dev):
-    """One extra HIP stream per device for the backward's independent kernels (fork/join by events: capturable)."""
-    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev)
-    return st
-
-
-_fused_bwd = _os.environ.get("KPGNN_FUSED_BWD", "0") == "1"
-# The LDS-staged forward kernel (aggregate_lds.hip) is opt-in: at K*D ~ 832 floats per node a tile's rows only fit
-# LDS hop by hop, the per-hop barriers then cost more than the dependent global loads they remove (measured
-# 170 us vs 114 us at N = 47k, K = 8, D = 104; profiles/r01/exp_lds_vs_global.log).  KPGNN_LDS_AGG=1 enables it.
-_no_lds_tiles = _os.environ.get("KPGNN_LDS_AGG", "0") != "1"
-
 
 def set_launch_timer(timer):
     global _timer
@@ -164,17 +138,6 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.n_dict = ptab.shape[0]
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
-    tiles = None
-    if x is not None and mode != MODE_GCN and D % 4 == 0 and D <= 256 and N > 0 and not _no_lds_tiles:
-        # LDS-staged kernel: component-aligned tiles of <= 3 nodes per sub-group of a 512-thread workgroup
-        g = 8
-        while g * 4 < D:
-            g <<= 1
-        node_cap = min(48, 3 * (512 // g), (3 * 512 * 4) // D)
-        if node_cap >= 8:
-            tiles = csr.component_tiles(node_cap, 2048)
-            d.tile_start, d.tile_flag, d.num_tiles = tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2]
-            d.tile_node_cap, d.tile_pair_cap = node_cap, 2048
     pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
     d.pre = _ptr(pre)
     if theta is not None:
@@ -244,24 +207,15 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     return gx, gt0, gtk
 
 
-def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None,
-                   fuse_pre=None, fuse_mode=MODE_SUM, fuse_ptab=None, want_gtheta=False):
+def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
-    With fuse_pre (= S saved by the forward) g is None: the kernel computes g = theta*gh*act'(S) itself, returns it,
-    and can reduce the theta gradient on the way.
-    Returns (gtable0, gtablek, gdict[, g, gtheta]), or None when the shape does not fit the LDS-resident kernel."""
+    kernel: 0 automatic, 1 register walk, 2 count-matrix product (parity tests).
+    Returns (gtable0, gtablek, gdict), or None when the shape fits neither kernel."""
     lib = _lib.load()
-    fused = fuse_pre is not None
-    if fused:
-        N, K, D = fuse_pre.shape
-        if D % 4 != 0 or D > 128 or K > 8:
-            return None
-        dev = fuse_pre.device
-    else:
-        g = g.contiguous()
-        N, K, D = g.shape
-        dev = g.device
+    g = g.contiguous()
+    N, K, D = g.shape
+    dev = g.device
     n0 = n_code0 if edges else 0
     nk = n_codek if (edges and K > 1) else 0
     ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n0, 1) if edges else 0, nk, n_dict)
@@ -271,22 +225,11 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n0, nk
     d.n_dict = n_dict
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
+    d.kernel = kernel
     if edges:
         d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
-    gth = None
-    if fused:
-        g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
-        d.fuse_pre, d.fuse_g, d.fuse_mode, d.fuse_ptab = fuse_pre.data_ptr(), g.data_ptr(), fuse_mode, _ptr(fuse_ptab)
-        d.theta, d.gh = theta.data_ptr(), gh.data_ptr()
-        if uid is not None:
-            d.uid, d.uid_stride = uid.data_ptr(), uid.stride(0)
-        if want_gtheta:
-            gth = torch.empty((K, D), dtype=torch.float32, device=dev)
-            d.gtheta = gth.data_ptr()
-    else:
-        d.g = g.data_ptr()
+    d.g = g.data_ptr()
     d.g_sn, d.g_sk = K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
-    d.max_pairs_per_segment = int(getattr(csr, "max_seg_pairs", 0) or 0) if edges else 1
     gt0 = gtk = gd = None
     if edges:
         gt0 = torch.empty((n0, D), dtype=torch.float32, device=dev)
@@ -305,12 +248,8 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(g)), "kpgnn_table_grad")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("table_grad_fused" if fused else "table_grad",
-                                   4 * N * K * D * (2 if fused else 1) + (4 * csr.active_pairs(K) if edges else 0)
-                                   + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0)
-                                   + (4 * N * D if fused else 0), e0, e1))
-    if fused:
-        return gt0, gtk, gd, g, gth
+            _timer.records.append(("table_grad", 4 * N * K * D + (4 * csr.active_pairs(K) if edges else 0)
+                                   + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0), e0, e1))
     return gt0, gtk, gd
 
 
@@ -413,22 +352,6 @@ class KHopAggregate(torch.autograd.Function):
         gtheta = gperiph = gdict = None
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        # --- fused backward pre-pass: one kernel computes g, the theta gradient, the edge-code table gradients
-        #     and the dictionary gradient (fused combine, P absent or in dictionary form, not GCN)
-        if fused and mode != MODE_GCN and not ctx.has_periph and _fused_bwd:
-            res = table_grad_raw(csr, None, ctx.n_code0, ctx.n_codek, edges=want_tables,
-                                 uid=uid if ctx.n_dict > 0 else None, n_dict=ctx.n_dict if want_gdict else 0,
-                                 theta=theta, gh=gout, fuse_pre=pre, fuse_mode=mode, fuse_ptab=ptab,
-                                 want_gtheta=ctx.needs_input_grad[5])
-            if res is not None:
-                gt0, gtk, gdict, g, gtheta = res
-                gx, _, _ = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, False,
-                                             slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
-                if ctx.n_slots:
-                    return (None, gt0, gtk, None, None, gtheta, None, gdict, None, None, None, None, None,
-                            *_slot_grads(ctx, gx))
-                return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, None, None, gtheta, None, gdict,
-                        None, None, None, None, None)
         if fused or need_act:
             g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
                                             want_gtheta=fused and ctx.needs_input_grad[5],
@@ -440,22 +363,14 @@ class KHopAggregate(torch.autograd.Function):
         # --- table gradients (edge codes + peripheral dictionary), column-private kernel
         gt0 = gtk = None
         tables_in_gather = False
-        side = main = None
         if want_tables or want_gdict:
             edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
             dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
             res = None
             if edges_here or dict_here:
-                # table_grad (latency / SALU bound walk) and aggregate_bwd (gather, issue bound) both only READ g:
-                # fork the former onto a side stream so the two overlap; joined below before anything is returned
-                if _overlap_bwd:
-                    main = torch.cuda.current_stream(g.device)
-                    side = _side_stream(g.device)
-                    side.wait_stream(main)
-                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                    res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
-                                         uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
-                                         theta=theta if fused else None, gh=gout if fused else None)
+                res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
+                                     uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
+                                     theta=theta if fused else None, gh=gout if fused else None)
             if res is not None:
                 gt0, gtk, gdict = res
             if want_tables and (res is None or not edges_here):
@@ -469,8 +384,6 @@ class KHopAggregate(torch.autograd.Function):
                 gdict = r2[2]
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
-        if side is not None:
-            main.wait_stream(side)
         if tables_in_gather:
             gt0, gtk = a0, ak
         geps = None
@@ -613,21 +526,54 @@ def table_gather_sum(table, bias, idx, col_offset):
 _I16 = "_kpgnn_idx16"
 
 
-def embedding_rows(weight, idx):
-    """weight[idx] for an integer index tensor [M] or [M,1] (the bodies' input embedding, input_encoder.py:21-22)
-    through the gather-sum kernels: unlike the framework's embedding backward (sort + unique_by_key with a host
-    read-back) this is free of host synchronisation, hence hipGraph-capturable.  The int16 copy of the index is
-    cached on the index tensor object."""
+class _ZeroRowGrad(torch.autograd.Function):
+    """Identity whose backward zeroes one row of the gradient: nn.Embedding(padding_idx=r) semantics for a table that
+    is read through the gather-sum kernels."""
+
+    @staticmethod
+    def forward(ctx, weight, row):
+        ctx.row = row
+        return weight.view_as(weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[ctx.row].zero_()
+        return g, None
+
+
+def embedding_rows(weight, idx, padding_idx=None):
+    """weight[idx] for an integer index tensor of any shape (the bodies' input embedding, input_encoder.py:21-22; the
+    layers' path encoding, KPGIN.py:92-93) through the gather-sum kernels: unlike the framework's embedding backward
+    (sort + unique_by_key with a host read-back, which FAULTS when a captured hipGraph replays it) this is free of
+    host synchronisation.  The 16-bit copy of the index is cached on the index tensor object; building it validates
+    the range once (one sync per index tensor, outside any capture), as nn.Embedding's device assert would.
+    padding_idx: that row receives no gradient (its forward value is whatever the table holds, zeros for nn.Embedding)."""
+    if idx.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8):
+        raise TypeError(f"embedding_rows: integer index expected, got {idx.dtype}")
+    R = weight.shape[0]
+    if R > 65536:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.KpgnnError(f"embedding table with {R} rows > 65536 falls back to the framework's embedding, whose "
+                                  "backward cannot be captured in a hipGraph (host read-back); run eagerly")
+        return torch.nn.functional.embedding(idx.long(), weight, padding_idx=padding_idx)
     rec = getattr(idx, _I16, None)
-    if rec is None or rec[0] != idx._version:
-        if weight.shape[0] > 32768:
-            return torch.nn.functional.embedding(idx, weight)
-        i16 = idx.reshape(-1, 1).to(torch.int16).contiguous()
+    if rec is None or rec[0] != (idx._version, R):
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.KpgnnError("embedding_rows: first use of an index tensor inside a hipGraph capture (its range "
+                                  "check needs a host sync); run one eager step on the batch before capturing")
+        flat = idx.reshape(-1, 1)
+        if flat.numel() and bool(((flat < 0) | (flat >= R)).any().item()):
+            raise IndexError(f"embedding index out of range for a table with {R} rows")
+        i64 = flat.long()
+        i16 = (i64 if R <= 32768 else i64 - 65536 * (i64 >= 32768)).to(torch.int16).contiguous()
         off = torch.zeros(1, dtype=torch.int32, device=idx.device)
-        rec = (idx._version, i16, off)
+        rec = ((idx._version, R), i16, off)
         try:
             setattr(idx, _I16, rec)
         except Exception:  # pragma: no cover
             pass
+    if padding_idx is not None and weight.requires_grad:
+        weight = _ZeroRowGrad.apply(weight, int(padding_idx))
     out = TableGatherSum.apply(weight, None, rec[1], rec[2])
     return out.view(*idx.shape, weight.shape[1])

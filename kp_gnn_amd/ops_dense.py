@@ -2,7 +2,6 @@
 
 The nn.BatchNorm1d modules stay where the reference has them (state_dict keys `mlp.1.*`, `norms.l.module.*`);
 only their training-mode arithmetic is routed here.  Eval mode (running statistics) uses torch's own GPU op."""
-import contextlib
 import ctypes
 
 import torch
@@ -77,20 +76,16 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None, None
 
 
-import os as _os
 # kpgnn_linear_fwd: y = x W^T + b and dx = dy W for tall-skinny x on the fp32 matrix cores.  Measured 21.8 us per
 # [47k,104] x [104,104] launch against 29 us for the BLAS library's kernel (profiles/r01): on by default for the shapes
 # it covers (I in {32, 64, 104, 128}, O % 4 == 0, contiguous operands, N >= 1024; O > 128 walks the outputs in
-# chunks of 128 over an LDS-resident x tile: 118 us vs the library's 146 us for [47k,104] x [104,936]); KPGNN_MFMA_LINEAR=0 keeps
-# the library.  The weight-gradient kernel (34 us vs the library's 139 us) is always on.
-_USE_MFMA_LINEAR = _os.environ.get("KPGNN_MFMA_LINEAR", "1") == "1"
+# chunks of 128 over an LDS-resident x tile: 118 us vs the library's 146 us for [47k,104] x [104,936]).  Other shapes go
+# to the BLAS library.  The weight-gradient kernel (34 us vs the library's 139 us) serves every shape up to 256 x 256.
 
 
 def _mfma_linear(x, w, bias, transposed=False):
     """y = x w^T + bias on kpgnn_linear_fwd (w: [O,I] contiguous), or y = x w with transposed=True (w: [I,O]).
     Returns None when the shape is not covered."""
-    if not _USE_MFMA_LINEAR:
-        return None
     lib = _lib.load()
     N, I = x.shape
     O = w.shape[1] if transposed else w.shape[0]
@@ -137,47 +132,17 @@ class LinearWgrad(torch.autograd.Function):
             dx = _mfma_linear(dy if dy.is_contiguous() else dy.contiguous(), weight.contiguous(), None, transposed=True)
             if dx is None:
                 dx = dy @ weight
-        # Weight gradients are leaves of the backward graph: nothing downstream waits for them until the optimiser.
-        # With overlap enabled (set_wgrad_overlap; the caller then owes a join_wgrad_stream() before it touches any
-        # .grad) the 1-block-per-CU MFMA kernel runs on a side stream next to the main stream's streaming kernels.
-        side = None
-        if _wgrad_overlap["on"]:
-            from .ops import _side_stream
-            main = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
-            side.wait_stream(main)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            dw = torch.empty((O, I), dtype=torch.float32, device=dev)
-            db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-            nb = lib.kpgnn_wgrad_workspace_bytes(O, I)
-            ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
-            d = _lib.WgradDesc()
-            d.N, d.O, d.I = N, O, I
-            d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
-            d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
-            with torch.cuda.device(dev):
-                _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(d), _stream(dy)), "kpgnn_linear_wgrad")
-        if side is not None:
-            _wgrad_overlap["pending"].append((dev, dy, x, ws))   # keep the operands alive until the join
+        dw = torch.empty((O, I), dtype=torch.float32, device=dev)
+        db = torch.empty((O,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        nb = lib.kpgnn_wgrad_workspace_bytes(O, I)
+        ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+        d = _lib.WgradDesc()
+        d.N, d.O, d.I = N, O, I
+        d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(d), _stream(dy)), "kpgnn_linear_wgrad")
         return dx, dw, db
-
-
-_wgrad_overlap = {"on": False, "pending": []}
-
-
-def set_wgrad_overlap(flag):
-    """Opt in to running the weight-gradient kernels on a side stream.  The caller must call join_wgrad_stream()
-    after backward and before reading or stepping any gradient (bench.py does, inside the captured graph)."""
-    _wgrad_overlap["on"] = bool(flag)
-
-
-def join_wgrad_stream():
-    pend = _wgrad_overlap["pending"]
-    if pend:
-        from .ops import _side_stream
-        for dev in {p[0] for p in pend}:
-            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
-        pend.clear()
 
 
 def linear(x, lin):

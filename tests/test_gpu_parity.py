@@ -25,6 +25,31 @@ def _close(a, b, name, rtol=RTOL, atol=ATOL):
     assert torch.allclose(a, b, rtol=rtol, atol=atol * scale), (name, float((a - b).abs().max()), scale)
 
 
+def _close_param_grads(params, ref_grads, name, rtol, atol):
+    """Every parameter gradient against the reference's, tensor by tensor.
+
+    |got - ref| <= rtol*|ref| + atol*max(|ref_k|_max, 0.1*gscale)   (gscale = largest gradient of the case)
+    so a tensor is held to its OWN magnitude as soon as it is within 10x of the largest one, and to 1/10 of the
+    old case-wide absolute tolerance otherwise: with atol = 1e-5 a tensor of magnitude 1e-3*gscale (alphas, eps,
+    pew / pcw, small embedding tables) is pinned to 0.1 %.  The floor is what fp32 summation order leaves on
+    these N-term reductions (measured ~5e-7*gscale on analytically-zero sums, see below).
+    Tensors whose REFERENCE gradient is below 3e-6*gscale are rounding noise of analytically-zero sums (the bias
+    of a Linear that feeds a BatchNorm, the never-trained path-encoding table): there the check is that ours is
+    noise as well."""
+    assert sorted(params) == sorted(ref_grads), name
+    gscale = max(float(g.abs().max()) for g in ref_grads.values())
+    for k, g in ref_grads.items():
+        got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        got = got.cpu()
+        gmax = float(g.abs().max()) if g.numel() else 0.0
+        err = float((got - g).abs().max()) if g.numel() else 0.0
+        if gmax <= 3e-6 * gscale:
+            assert float(got.abs().max()) <= 1e-5 * gscale, (name, k, "noise tensor", float(got.abs().max()), gscale)
+            continue
+        scale = max(gmax, 0.1 * gscale)
+        assert torch.allclose(got, g, rtol=rtol, atol=atol * scale), (name, k, err, gmax, gscale)
+
+
 # ----------------------------------------------------------------------------- K-hop CSR (integer: bit-exact)
 def _csr_reference(edge_index, edge_attr, N):
     """numpy restatement of the CSR contract in include/kpgnn.h (stable order inside a segment)."""
@@ -123,13 +148,7 @@ def test_layers_match_reference_goldens(golden_dir):
         _close(x.grad, case["grad_x"], name + ":grad_x")
         if periph is not None:
             _close(periph.grad, case["grad_peripheral_attr"], name + ":grad_periph")
-        gscale = max(float(g.abs().max()) for g in case["param_grads"].values())
-        params = dict(layer.named_parameters())
-        assert sorted(params) == sorted(case["param_grads"]), name
-        for k, g in case["param_grads"].items():
-            got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
-            assert torch.allclose(got.cpu(), g, rtol=RTOL, atol=ATOL * max(1.0, gscale)), \
-                (name, k, float((got.cpu() - g).abs().max()), gscale)
+        _close_param_grads(dict(layer.named_parameters()), case["param_grads"], name, RTOL, ATOL)
         sd = layer.state_dict()
         for k, v in case["state_dict_after"].items():
             if "running" in k:
@@ -309,13 +328,7 @@ def test_bodies_match_reference_goldens(golden_dir):
         loss.backward()
         _close(score, case["score"], name + ":score", rtol=2e-4, atol=2e-5)
         _close(loss, case["loss"], name + ":loss", rtol=2e-4, atol=2e-5)
-        gscale = max(float(g.abs().max()) for g in case["param_grads"].values())
-        params = dict(model.named_parameters())
-        assert sorted(params) == sorted(case["param_grads"]), name
-        for k, g in case["param_grads"].items():
-            got = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
-            assert torch.allclose(got.cpu(), g, rtol=2e-3, atol=5e-5 * max(1.0, gscale)), \
-                (name, k, float((got.cpu() - g).abs().max()), gscale)
+        _close_param_grads(dict(model.named_parameters()), case["param_grads"], name, 2e-3, 5e-5)
 
 
 # ----------------------------------------------------------------------------- multi-table gather-sum
@@ -532,86 +545,6 @@ def test_kgin_simulation_layer_vs_oracle():
         _close(v.grad, p[k].grad, "grad " + k, atol=3e-5)
 
 
-def test_component_tiles_partition():
-    """Tiles are contiguous, cover [0,N), respect the caps, and unflagged tiles are closed under the K-hop edges."""
-    from kp_gnn_amd.batch import synthetic_zinc_batch
-    dev = _dev()
-    b = synthetic_zinc_batch(200, seed0=3, K=8).to(dev)
-    csr = b.build_csr()
-    for node_cap, pair_cap in ((48, 2048), (24, 400), (8, 64)):
-        ts, tf, T = csr.component_tiles(node_cap, pair_cap)
-        ts, tf = ts.cpu().numpy(), tf.cpu().numpy()
-        assert ts[0] == 0 and ts[T] == csr.N and (np.diff(ts) > 0).all()
-        ei = b.edge_index.cpu().numpy()
-        tile_of = np.searchsorted(ts, np.arange(csr.N), side="right") - 1
-        rp = csr.rowptr_dst.cpu().numpy()
-        for t in range(T):
-            n0, n1 = ts[t], ts[t + 1]
-            assert n1 - n0 <= node_cap
-            if not tf[t]:
-                assert rp[n1 * csr.K] - rp[n0 * csr.K] <= pair_cap
-        crossing = tile_of[ei[0]] != tile_of[ei[1]]
-        assert not (crossing & (tf[tile_of[ei[0]]] == 0)).any() and not (crossing & (tf[tile_of[ei[1]]] == 0)).any()
-    assert (csr.component_tiles(48, 2048)[1] == 0).all()       # molecules always fit
-    assert csr.component_tiles(8, 64)[1].any()                  # tiny caps force the spill path
-
-
-def test_lds_forward_equals_global_gather_forward():
-    """The LDS-staged forward kernel (incl. flagged spill tiles) against the global-gather kernel, bitwise-close."""
-    from kp_gnn_amd import _lib, ops
-    from kp_gnn_amd.batch import synthetic_zinc_batch
-    dev = _dev()
-    saved = ops._no_lds_tiles
-    b = synthetic_zinc_batch(64, seed0=11, K=8).to(dev)
-    csr = b.build_csr()
-    N = b.num_nodes
-    for D, k in ((104, 8), (104, 3), (24, 8), (96, 1), (16, 5)):
-        g = torch.Generator().manual_seed(D + k)
-        x = torch.randn(N, 8, D, generator=g).to(dev)[:, :k]
-        t0, tk = torch.randn(5, D, generator=g).to(dev), torch.randn(52, D, generator=g).to(dev)
-        P = torch.randn(N, 8, D, generator=g).to(dev)[:, :k]
-        theta = torch.softmax(torch.randn(k, D, generator=g), 0).to(dev)
-        uid = torch.randint(0, 9, (N, 8), generator=g).to(torch.int32).to(dev)[:, :k]
-        ptab = torch.randn(9, D, generator=g).to(dev)
-        eps = torch.tensor([0.3], device=dev)
-        xb = torch.randn(D, generator=g).to(dev)
-        cases = [
-            dict(mode=_lib.MODE_GINPLUS, periph=None, theta=theta, ptab=ptab, uid=uid, want_pre=True),
-            dict(mode=_lib.MODE_GINPLUS, periph=P, theta=None, want_pre=True),
-            dict(mode=_lib.MODE_GIN, periph=P, theta=None, eps=eps, xbias=xb, want_pre=False),
-            dict(mode=_lib.MODE_SUM, periph=None, theta=None, tables=False, want_pre=False),
-        ]
-        for c in cases:
-            outs = []
-            for no_lds in (True, False):
-                ops._no_lds_tiles = no_lds
-                tabs = c.get("tables", True)
-                o, pre = ops.aggregate_fwd_raw(csr, k, c["mode"], x, t0 if tabs else None, tk if tabs else None,
-                                               c.get("periph"), c.get("eps"), c.get("theta"), c.get("xbias"),
-                                               c["want_pre"], ptab=c.get("ptab"), uid=c.get("uid"))
-                outs.append((o, pre))
-            ops._no_lds_tiles = saved
-            _close(outs[1][0], outs[0][0], f"out D={D} k={k} mode={c['mode']}", rtol=1e-5, atol=1e-6)
-            if c["want_pre"]:
-                _close(outs[1][1], outs[0][1], "pre", rtol=1e-5, atol=1e-6)
-    # spill path: caps so small that components are chopped (gathers leave the tile)
-    ts, tf, T = csr.component_tiles(8, 64)
-    import ctypes
-    x = torch.randn(N, 8, 104, device=dev)
-    ref, _ = (lambda: (setattr(ops, "_no_lds_tiles", True), ops.aggregate_fwd_raw(csr, 8, _lib.MODE_SUM, x, None, None, None, None, None, None, False))[1])()
-    ops._no_lds_tiles = saved
-    lib = _lib.load()
-    out = torch.empty_like(ref)
-    d = _lib.AggFwdDesc()
-    d.N, d.K, d.D, d.K_csr, d.mode = N, 8, 104, 8, _lib.MODE_SUM
-    d.rowptr, d.col, d.code = csr.rowptr_dst.data_ptr(), csr.col_dst.data_ptr(), csr.code_dst.data_ptr()
-    d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
-    d.out, d.o_sn, d.o_sk = out.data_ptr(), out.stride(0), out.stride(1)
-    d.tile_start, d.tile_flag, d.num_tiles, d.tile_node_cap, d.tile_pair_cap = ts.data_ptr(), tf.data_ptr(), T, 8, 64
-    _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "fwd")
-    _close(out, ref, "spill tiles", rtol=1e-5, atol=1e-6)
-
-
 def test_attention_combine_hip_vs_reference_goldens(golden_dir):
     """AttentionCombine on the HIP kernels (recurrence, softmax, BPTT, MFMA weight grads) vs the reference's nn.LSTM."""
     from kp_gnn_amd.layers import AttentionCombine
@@ -690,44 +623,6 @@ def test_mfma_linear_forward_kernel(N, O, I):
     _close(dx, dy @ wd, "dx", rtol=2e-4, atol=2e-5)
 
 
-def test_fused_backward_prepass_equals_two_kernel_path():
-    """kpgnn_table_grad with fuse_pre (g, theta grad, table grads, dictionary grads in one launch) == combine_bwd +
-    table_grad, on KP-GIN+ layers with a dictionary P (stacked and slot inputs)."""
-    from kp_gnn_amd import ops
-    from kp_gnn_amd.layers import KPGINPlusConv
-    from kp_gnn_amd.ops import DictPeripheral
-    dev = _dev()
-    N, E, K, H = 91, 800, 6, 104
-    ei, ea = _random_khop(N, E, K, seed=51, n0=4, nk=8)
-    ei, ea = ei.to(dev), ea.to(dev)
-    torch.manual_seed(9)
-    layer = KPGINPlusConv(H, H, K, num_hop1_edge=2, num_pe=8, combine="geometric").to(dev)
-    with torch.no_grad():
-        layer.combine.alphas.copy_(torch.randn(H) * 0.5)
-    table = torch.randn(5, H, device=dev)
-    uid = torch.randint(0, 5, (N, K), device=dev, dtype=torch.int32)
-    hs = [torch.randn(N, H, device=dev) for _ in range(K)]
-    w = torch.randn(N, H, device=dev)
-    res = []
-    saved = ops._fused_bwd
-    try:
-        for fused in (False, True):
-            ops._fused_bwd = fused
-            layer.zero_grad()
-            t = table.clone().requires_grad_(True)
-            hh = [h.clone().requires_grad_(True) for h in hs]
-            out = layer.forward_slots(hh, ei, ea, None, DictPeripheral(t, uid))
-            (out * w).sum().backward()
-            res.append(([h.grad for h in hh], t.grad, {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}))
-    finally:
-        ops._fused_bwd = saved
-    for a, b in zip(res[1][0], res[0][0]):
-        _close(a, b, "grad slot", rtol=1e-5, atol=2e-6)
-    _close(res[1][1], res[0][1], "grad dict table", atol=3e-5)
-    for k in res[0][2]:
-        _close(res[1][2][k], res[0][2][k], "grad " + k, atol=3e-5)
-
-
 @pytest.mark.parametrize("N,K,DI,DO", [(1000, 8, 13, 13), (77, 6, 20, 20), (4099, 16, 6, 6), (130, 3, 5, 9),
                                         (64, 1, 32, 32), (129, 4, 16, 16), (1, 2, 3, 3), (300, 2, 17, 4), (650, 16, 15, 15)])
 @pytest.mark.parametrize("head", ["proj", "theta", "plain", "proj_nobias_odd"])
@@ -799,15 +694,14 @@ def test_geo_theta_kernel_vs_reference_formula(K, D):
     _close(m(x.to(dev)), ref_m(x), "combine", rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("kernel", ["walk", "mfma", "bf16"])
+@pytest.mark.parametrize("kernel", ["walk", "mfma"])
 @pytest.mark.parametrize("D,dict_mode", [(104, "theta_gh"), (104, "rows"), (40, "none"), (13, "rows"), (64, "theta_gh")])
-def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode, monkeypatch):
-    """The three table-gradient kernels (register walk, fp32 count-matrix MFMA, exact bf16x3 count-matrix MFMA) against
-    torch index_add_ on the same (code, row) pairs: edge-code tables and both dictionary sources."""
+def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode):
+    """Both table-gradient kernels (register walk, fp32 count-matrix MFMA; kpgnn_table_grad_desc.kernel forces one)
+    against torch index_add_ on the same (code, row) pairs: edge-code tables and both dictionary sources."""
     from kp_gnn_amd import ops
     from kp_gnn_amd.khop_csr import KHopCSR
     dev = _dev()
-    monkeypatch.setenv("KPGNN_TG_KERNEL", kernel)
     g0 = torch.Generator().manual_seed(D * 7 + len(dict_mode))
     N, K, E = 333, 8, 6000
     ei = torch.randint(0, N, (2, E), generator=g0)
@@ -823,7 +717,7 @@ def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode, monkeypat
         kw = dict(uid=uid.to(dev), n_dict=U, theta=theta.to(dev), gh=gh.to(dev))
     elif dict_mode == "rows":
         kw = dict(uid=uid.to(dev), n_dict=U)
-    res = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **kw)
+    res = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, kernel={"walk": 1, "mfma": 2}[kernel], **kw)
     assert res is not None
     gt0, gtk, gd = res
     e, k = torch.nonzero(ea, as_tuple=True)
@@ -837,3 +731,85 @@ def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode, monkeypat
         src = (theta.unsqueeze(0) * gh.unsqueeze(1)) if dict_mode == "theta_gh" else gt
         refd = torch.zeros(U, D).index_add_(0, uid.reshape(-1).long(), src.reshape(-1, D))
         _close(gd, refd, "gdict", rtol=2e-4, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- hipGraph capture: replay == eager
+def _small_body(model_name, combine, K, L, H):
+    import argparse
+    from kp_gnn_amd import body as B
+    from kp_gnn_amd.layers import make_gnn_layer
+    ns = argparse.Namespace(model_name=model_name, hidden_size=H, K=K, num_layer=L, num_hop1_edge=3, max_pe_num=50,
+                            combine=combine, eps=0., train_eps=False, aggr="add")
+    torch.manual_seed(3)
+    gnn = B.make_GNN(ns)(num_layer=L, gnn_layer=make_gnn_layer(ns), JK="concat", norm_type="Batch",
+                         init_emb=B.EmbeddingEncoder(21, H), residual=True, virtual_node=False, use_rd=False,
+                         num_hop1_edge=3, max_edge_count=50, max_hop_num=6, max_distance_count=50, drop_prob=0.0)
+    return B.GraphRegression(gnn, "sum")
+
+
+@pytest.mark.parametrize("model_name,combine,nonzero_pe", [("KPGINPlus", "geometric", False), ("KPGINPlus", "attention", False),
+                                                           ("KPGIN", "geometric", True), ("KPGIN", "attention", False)])
+def test_hipgraph_replay_equals_eager(model_name, combine, nonzero_pe):
+    """A captured hipGraph of fwd+bwd replays to the SAME bits the eager launches produce (score, loss and every
+    parameter gradient), including a model whose path-encoding table is live (non-zero pe_attr): that lookup used to go
+    through the framework's embedding backward, whose thrust unique_by_key host read-back faults on replay
+    (round 1, gpurun_out/bench_17.log) - it now runs on the gather-sum kernels."""
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    K, L, H = 3, 3, 24
+    model = _small_body(model_name, combine, K, L, H).to(dev).train()
+    b = synthetic_zinc_batch(24, seed0=99, K=K).to(dev)
+    if nonzero_pe:
+        g = torch.Generator().manual_seed(5)
+        b.pe_attr = torch.randint(0, 50, b.pe_attr.shape, generator=g).to(dev)
+    b.build_csr()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def fwd_bwd():
+        score = model(b)
+        loss = (score.squeeze() - b.y.squeeze()).abs().mean()
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        return score, loss, grads
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd()                                   # warms the caches that sync (index packing, CSR, range checks)
+        score_e, loss_e, grads_e = fwd_bwd()
+        score_e, loss_e = score_e.clone(), loss_e.clone()
+        grads_e = [None if g is None else g.clone() for g in grads_e]
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        score_g, loss_g, grads_g = fwd_bwd()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(score_g, score_e) and torch.equal(loss_g, loss_e)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    for n, ge, gg in zip(names, grads_e, grads_g):
+        assert (ge is None) == (gg is None), n
+        if ge is not None:
+            assert torch.equal(ge, gg), (n, float((ge - gg).abs().max()))
+    if nonzero_pe:
+        gpe = dict(zip(names, grads_g))["embedding_model.gnns.0.hopk_node_path_emb.weight"]
+        assert gpe is not None and float(gpe.abs().max()) > 0 and float(gpe[0].abs().max()) == 0   # live, padding row untouched
+
+
+def test_embedding_rows_validates_range_and_padding():
+    from kp_gnn_amd.ops import embedding_rows
+    dev = _dev()
+    w = torch.randn(7, 8, device=dev, requires_grad=True)
+    with pytest.raises(IndexError):
+        embedding_rows(w, torch.tensor([0, 7], device=dev))
+    with pytest.raises(IndexError):
+        embedding_rows(w, torch.tensor([-1, 2], device=dev))
+    idx = torch.tensor([[0, 3], [3, 6]], device=dev)
+    out = embedding_rows(w, idx, padding_idx=0)
+    assert out.shape == (2, 2, 8) and torch.equal(out, w.detach()[idx])
+    out.sum().backward()
+    ref = torch.zeros(7, 8)
+    ref[3] = 2
+    ref[6] = 1
+    assert torch.equal(w.grad.cpu(), ref)            # row 0 (padding) receives nothing
