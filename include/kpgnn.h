@@ -265,16 +265,18 @@ int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
 int kpgnn_table_gather_sum_bwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Training-mode BatchNorm1d (+ optional ReLU) over [N, C] rows, forward and backward.  These are the
- * nn.BatchNorm1d calls of KPGINPlusConv.mlp (KPGINplus.py:25-30), GINEConv.mlp (gine.py:31-38) and of the
- * bodies' per-layer norm (models/GNNs.py:104,431): at C ~ 100 and N ~ 50k the framework's kernels take
- * 100-140 us per pass (40 % of the training step); these stream the tensor at HBM speed.  Statistics are
- * accumulated around a per-column pivot (row 0) so that E[x^2]-E[x]^2 does not cancel; partial sums leave
- * through a per-block slab reduced in block order (deterministic).
- *   fwd:  mean, invstd (biased var, eps) -> z = [relu]( (x-mean)*invstd*gamma + beta ); running stats updated
- *         in place with `momentum` and the unbiased variance, exactly as nn.BatchNorm1d.
- *   bwd:  dy = dz * [pre-activation > 0 if relu];  dbeta = sum dy; dgamma = sum dy*xhat;
- *         dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N).
+ * Training-mode BatchNorm1d (+ optional ReLU, + optional residual) over [N, C] rows, forward and backward.  These
+ * are the nn.BatchNorm1d calls of KPGINPlusConv.mlp (KPGINplus.py:25-30), GINEConv.mlp (gine.py:31-38) and of
+ * the bodies' per-layer norm (models/GNNs.py:104,431): at C ~ 100 and N ~ 50k the framework's kernels take
+ * 100-140 us per pass; these stream the tensor at HBM speed around a column-statistics slot (above):
+ *   fwd:  [stats pass: sum x, sum x^2 -> stat_slot, skipped when stats_ready - the producer of x filled the slot]
+ *         apply pass: mean, invstd (biased var, eps) from the slot, z = [relu]( (x-mean)*invstd*gamma + beta )
+ *         (+ residual); running stats updated in place with `momentum` and the unbiased variance, exactly as
+ *         nn.BatchNorm1d; with out_slot the statistics of z are accumulated for a following BatchNorm.
+ *   bwd:  dy = dz * [pre-activation > 0 if relu];  reduce pass: dbeta = sum dy, dgamma = sum dy*xhat -> stat_slot
+ *         (reduce_only stops here: a fused consumer applies them, kpgnn_linear_bn pro 2);
+ *         apply pass: dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N).
+ * Every slot must be all zero when the call is issued and is left dirty.  C <= 256.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct kpgnn_bn_desc {
     int64_t N;
@@ -286,7 +288,9 @@ typedef struct kpgnn_bn_desc {
     float* mean; float* invstd;             /* device [C] outputs (saved for backward) */
     float* z;  int64_t z_stride;            /* device [N,C] output */
     const float* residual; int64_t r_stride;/* optional: z += residual (after the activation) */
-    void* workspace; size_t workspace_bytes;/* >= kpgnn_bn_workspace_bytes(C) */
+    double* stat_slot;                      /* device, kpgnn_stat_slot_bytes(C): statistics of x */
+    int32_t stats_ready;                    /* 1: stat_slot already holds sum x / sum x^2 (no stats pass) */
+    double* out_slot;                       /* optional (zeroed) slot receiving the statistics of z, or NULL */
     int64_t* num_batches_tracked;           /* device scalar, += 1 per call, or NULL (nn.BatchNorm1d's counter) */
 } kpgnn_bn_desc;
 
@@ -296,14 +300,27 @@ typedef struct kpgnn_bn_bwd_desc {
     const float* x;  int64_t x_stride;
     const float* dz; int64_t dz_stride;
     const float* gamma; const float* beta; const float* mean; const float* invstd;
-    float* dx; int64_t dx_stride;
-    float* dgamma; float* dbeta;            /* device [C] (overwritten) */
-    void* workspace; size_t workspace_bytes;
+    float* dx; int64_t dx_stride;           /* NULL with reduce_only */
+    float* dgamma; float* dbeta;            /* device [C] (overwritten); NULL with reduce_only */
+    double* stat_slot;                      /* device, kpgnn_stat_slot_bytes(C), zero on entry */
+    int32_t reduce_only;
 } kpgnn_bn_bwd_desc;
 
-size_t kpgnn_bn_workspace_bytes(int32_t C);
 int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);
 int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Column-statistics slots.  BatchNorm needs batch-wide column sums; instead of a reduction kernel between the
+ * producer and the consumer of a tensor, the producing kernel's blocks add their partial sums (fp64 atomics) to a
+ * slot and the consuming kernel finishes mean / invstd (or the backward's dbeta / dgamma) from it in its prologue.
+ *   slot = double[KPGNN_STAT_REPLICAS][2][C]  (block b adds to replica b % KPGNN_STAT_REPLICAS: same-address
+ *   atomics serialise on this hardware), ALL ZERO before the producing launch; the calls leave it dirty - the
+ *   caller zeroes its slots in bulk (one hipMemsetAsync per training step over an arena of slots).
+ * Per block the sums are formed in a fixed order; only the order of the <= grid/8 fp64 adds per address varies
+ * between runs (below 2^-52 relative: invisible after rounding to fp32 except on exact ties).
+ * ---------------------------------------------------------------------------------------------- */
+#define KPGNN_STAT_REPLICAS 8
+size_t kpgnn_stat_slot_bytes(int32_t C);   /* sizeof(double) * KPGNN_STAT_REPLICAS * 2 * C */
 
 /* ------------------------------------------------------------------------------------------------
  * Weight / bias gradient of y = x W^T + b for tall-skinny activations (N ~ 50k rows, <= 256 features):
@@ -322,10 +339,17 @@ typedef struct kpgnn_wgrad_desc {
     float* dw;                  /* device [O,I] contiguous (overwritten) */
     float* db;                  /* device [O] (overwritten) or NULL */
     void* workspace; size_t workspace_bytes;  /* >= kpgnn_wgrad_workspace_bytes(O, I) */
+    /* Optional transform of x on load: x' = [relu]((x - x_mean) * x_invstd * x_gamma + x_beta), i.e. the Linear's real
+     * input when that was a BatchNorm(+ReLU) output the forward never materialised (kpgnn_linear_bn pro 1). */
+    const float* x_mean; const float* x_invstd; const float* x_gamma; const float* x_beta;   /* device [I] or all NULL */
+    int32_t x_relu;
 } kpgnn_wgrad_desc;
 
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);
 int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream);
+/* Two weight gradients with the same (O, I) in ONE launch + one ordered reduction (the two Linears of a
+ * Linear-BatchNorm-ReLU x2 MLP): workspace >= 2 * kpgnn_wgrad_workspace_bytes(O, I), taken from a. */
+int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wgrad_desc* b, kpgnn_stream_t stream);
 
 /* y = x W^T (+ b) for tall-skinny x ([N, I], N ~ 50k, I, O <= 256) on the fp32 matrix cores: the nn.Linear
  * forward of the layers' MLPs, and - called with W^T - their input gradient dx = dy W.  Each wave keeps its
@@ -343,6 +367,45 @@ typedef struct kpgnn_linear_desc {
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
+
+/* The same GEMM with BatchNorm work folded into the tile's load and store phases (csrc/lin_fused.h), so that the
+ * Linear-BatchNorm-ReLU x2 MLP (KPGINplus.py:25-30, gine.py:31-38) is 3 launches forward and 5 backward instead of
+ * 8 + 14, with 6 fewer passes over [N,H]:
+ *   pro 0: x as is.
+ *   pro 1: x' = [pro_relu]((x - mean)*invstd*in_gamma + in_beta) applied while the tile is loaded; mean / invstd are
+ *          finished from in_slot (sum x, sum x^2 left there by the launch that produced x, epi 1); the launch writes
+ *          in_mean / in_invstd and updates running_mean / running_var / num_batches_tracked like kpgnn_bn_fwd.
+ *   pro 2: BatchNorm BACKWARD on load: x is dz, x2 the BatchNorm's forward input, in_mean / in_invstd its saved
+ *          statistics, in_slot holds (sum dzm, sum dzm*xhat) (kpgnn_bn_bwd reduce_only, or epi 2 of the previous
+ *          launch); the tile becomes dy = gamma*invstd*(dzm - s0/N - xhat*s1/N) with dzm = dz * [bn(x2) > 0 if
+ *          pro_relu]; dy is also written to xt (the weight-gradient kernel reads it); dgamma / dbeta are written.
+ *   epi 0: y stored as is.
+ *   epi 1: + (sum y, sum y^2) per column into out_slot.
+ *   epi 2: y is masked by the ReLU of the BatchNorm whose input was e_x (y = 0 where bn_e(e_x) <= 0) and
+ *          (sum y, sum y*xhat_e) go to out_slot: the backward reduce of that BatchNorm.
+ * x, x2, xt, e_x, y contiguous and 16-B aligned; I in {32, 64, 96, 104, 128}; O % 4 == 0, O <= 128.
+ * KPGNN_ELIMIT when the shape is not covered.  Slots: zero on entry (out_slot), dirty on return. */
+typedef struct kpgnn_linear_bn_desc {
+    int64_t N;
+    int32_t O, I;
+    const float* x; const float* w; const float* bias; float* y;
+    int32_t w_transposed;
+    int32_t pro, epi, pro_relu;
+    const double* in_slot;
+    const float* in_gamma; const float* in_beta;
+    float in_eps, momentum;
+    float* in_mean; float* in_invstd;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    const float* x2; float* xt; float* dgamma; float* dbeta;
+    double* out_slot;
+    const float* e_x; const float* e_mean; const float* e_invstd; const float* e_gamma; const float* e_beta;
+} kpgnn_linear_bn_desc;
+
+int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t stream);
+
+/* Identifier of the capture the stream is part of (hipStreamGetCaptureInfo), 0 when it is not capturing: lets a
+ * caller that zeroes its statistics slots once per step put that memset into every graph it captures. */
+int kpgnn_stream_capture_id(kpgnn_stream_t stream, uint64_t* id);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention hop-combine (reference layers/combine.py:8-27): a 1-layer bidirectional LSTM with hidden size K

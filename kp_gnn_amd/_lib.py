@@ -75,7 +75,7 @@ class BnDesc(ctypes.Structure):
         ("x", c_vp), ("x_stride", c_i64), ("gamma", c_vp), ("beta", c_vp),
         ("running_mean", c_vp), ("running_var", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("z", c_vp), ("z_stride", c_i64), ("residual", c_vp), ("r_stride", c_i64),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("num_batches_tracked", c_vp),
+        ("stat_slot", c_vp), ("stats_ready", c_i32), ("out_slot", c_vp), ("num_batches_tracked", c_vp),
     ]
 
 
@@ -85,7 +85,7 @@ class BnBwdDesc(ctypes.Structure):
         ("x", c_vp), ("x_stride", c_i64), ("dz", c_vp), ("dz_stride", c_i64),
         ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("dx", c_vp), ("dx_stride", c_i64), ("dgamma", c_vp), ("dbeta", c_vp),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("stat_slot", c_vp), ("reduce_only", c_i32),
     ]
 
 
@@ -94,6 +94,22 @@ class WgradDesc(ctypes.Structure):
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("dy", c_vp), ("dy_stride", c_i64), ("x", c_vp), ("x_stride", c_i64),
         ("dw", c_vp), ("db", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("x_mean", c_vp), ("x_invstd", c_vp), ("x_gamma", c_vp), ("x_beta", c_vp), ("x_relu", c_i32),
+    ]
+
+
+class LinearBnDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("O", c_i32), ("I", c_i32),
+        ("x", c_vp), ("w", c_vp), ("bias", c_vp), ("y", c_vp),
+        ("w_transposed", c_i32), ("pro", c_i32), ("epi", c_i32), ("pro_relu", c_i32),
+        ("in_slot", c_vp), ("in_gamma", c_vp), ("in_beta", c_vp),
+        ("in_eps", ctypes.c_float), ("momentum", ctypes.c_float),
+        ("in_mean", c_vp), ("in_invstd", c_vp),
+        ("running_mean", c_vp), ("running_var", c_vp), ("num_batches_tracked", c_vp),
+        ("x2", c_vp), ("xt", c_vp), ("dgamma", c_vp), ("dbeta", c_vp),
+        ("out_slot", c_vp),
+        ("e_x", c_vp), ("e_mean", c_vp), ("e_invstd", c_vp), ("e_gamma", c_vp), ("e_beta", c_vp),
     ]
 
 
@@ -147,11 +163,14 @@ SIGNATURES = {
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),
     "kpgnn_combine_bwd": (ctypes.c_int, [ctypes.POINTER(CombineBwdDesc), c_vp]),
-    "kpgnn_bn_workspace_bytes": (ctypes.c_size_t, [c_i32]),
     "kpgnn_bn_fwd": (ctypes.c_int, [ctypes.POINTER(BnDesc), c_vp]),
     "kpgnn_bn_bwd": (ctypes.c_int, [ctypes.POINTER(BnBwdDesc), c_vp]),
     "kpgnn_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
+    "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
+    "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
+    "kpgnn_stat_slot_bytes": (ctypes.c_size_t, [c_i32]),
+    "kpgnn_stream_capture_id": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),

@@ -368,6 +368,8 @@ class GNNPlus(_KHopBody):
                          max_distance_count, JK, norm_type, virtual_node, residual, use_rd, wo_peripheral_edge,
                          wo_peripheral_configuration, drop_prob)
         self.gnns = nn.ModuleList(gnn_layer)
+        for g in self.gnns:
+            g._kp_emit_out_stats = True      # norms[l] follows every layer: its statistics come out of the layer's last kernel
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -424,6 +426,8 @@ class GNNPrime(_KHopBody):
         self.khop_gnns = nn.ModuleList(copy.deepcopy(gnn_layer) for _ in range(num_l1_layer))
         gine = GINEConv(self.hidden_size, self.hidden_size, num_hop1_edge=num_hop1_edge)
         self.gins = nn.ModuleList(copy.deepcopy(gine) for _ in range(self.num_l2_layer))
+        for g in self.gins:
+            g._kp_emit_out_stats = True
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -68,7 +68,7 @@ def build_hip(force=False):
         for f in os.listdir(OBJ):
             if f.endswith(".hip.o"):
                 os.remove(os.path.join(OBJ, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 1), len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(HIPCC, HIP_FLAGS, s), srcs))
     _run([HIPCC, "-shared", "--offload-arch=gfx950", "-o", HIP_LIB] + objs)
     return HIP_LIB

@@ -1,7 +1,12 @@
 // Training-mode BatchNorm1d (+ReLU, +residual) over [N, C] rows for gfx950.  Contract: include/kpgnn.h.
-// HBM-bound streaming: stats pass (read x) -> ordered slab reduce -> apply pass (read x, write z); backward the
-// same shape (reduce pass reads x, dz; apply pass reads x, dz, writes dx).  A sub-group of G lanes spans the C
-// columns 16 B wide; sub-groups stride over rows; per-thread partials are register-resident.
+// HBM-bound streaming kernels around a column-statistics slot (kpgnn.h, "Column-statistics slots"):
+//   forward   [stats: sum x, sum x^2 -> slot]  ->  apply: finish mean / invstd from the slot, z = bn(x) (+relu, +residual),
+//             optionally the statistics of z into a second slot (the next BatchNorm's stats pass disappears)
+//   backward  reduce: sum dy, sum dy*xhat -> slot  ->  apply: dx, dgamma, dbeta
+// The stats / reduce half is skipped when the producer of the tensor has already filled the slot (the fused linear
+// kernels do, lin_fused.h).  Round 1 had a slab + an ordered slab-reduce launch between the halves (3 launches per
+// direction, ~4.7 us each at any size); the slot makes it 2, or 1.
+// A sub-group of G lanes spans the C columns 16 B wide; sub-groups stride over rows; partial sums are fp64 registers.
 #include <initializer_list>
 
 #include "kpgnn_common.h"
@@ -10,7 +15,7 @@ namespace kpgnn {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kStatBlocks = 512;   // partial-sum slabs
+constexpr int kProducerBlocks = 512;   // blocks of a launch that adds to a slot: 512 / 8 replicas = 64 adds per address
 
 template <int VEC> struct VT;
 template <> struct VT<1> { using T = float; };
@@ -31,47 +36,50 @@ struct BnParams {
     const float* x; int64_t xs;
     const float* dz; int64_t dzs;
     const float* gamma; const float* beta;
-    float* rmean; float* rvar;
+    float* rmean; float* rvar; int64_t* nbt;
     float* mean; float* invstd;        // fwd: outputs; bwd: inputs
     float* z; int64_t zs;              // fwd output / bwd dx
     const float* res; int64_t rs;
-    float* slab;                       // [gridDim.x][2][C]
-    float* sums;                       // [2][C] reduced
-    int64_t* nbt;                      // num_batches_tracked or NULL
+    const double* in_slot;             // consumer side
+    double* out_slot;                  // producer side
     float* dgamma; float* dbeta;
 };
 
-// Block reduction of per-thread (a,b)[VEC] over the row-lanes, then one slab row per block.
-// (Letting the last block to finish add the slab up in-kernel was tried: one block pulling 512 x 2C partials through
-//  L2 takes far longer than the ~4.6 us launch of the 2C/16-block ordered slab_reduce it would save.)
+__device__ __forceinline__ double slot_sum(const double* slot, int C, int which, int c) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < KPGNN_STAT_REPLICAS; ++r) s += slot[((int64_t)r * 2 + which) * C + c];
+    return s;
+}
+
+// Block reduction of per-thread (a,b)[VEC] over the row lanes (fixed order), then 2C fp64 atomics into this block's replica.
 template <int VEC, int G>
-__device__ __forceinline__ void block_to_slab(const BnParams& p, float (&a)[VEC], float (&b)[VEC], int c0, bool col_ok) {
-    __shared__ float red[2][kBlock / G][G * VEC];
+__device__ __forceinline__ void block_to_slot(double* slot, int C, const double (&a)[VEC], const double (&b)[VEC], int c0, bool col_ok) {
+    __shared__ double red[2][kBlock / G][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G;
     for (int q = 0; q < VEC; ++q) { red[0][rl][sl * VEC + q] = a[q]; red[1][rl][sl * VEC + q] = b[q]; }
     __syncthreads();
-    if (rl == 0 && col_ok) {
-        for (int q = 0; q < VEC; ++q) {
-            float s0 = 0.f, s1 = 0.f;
-            for (int r = 0; r < kBlock / G; ++r) { s0 += red[0][r][sl * VEC + q]; s1 += red[1][r][sl * VEC + q]; }
-            p.slab[((int64_t)blockIdx.x * 2 + 0) * p.C + c0 + q] = s0;
-            p.slab[((int64_t)blockIdx.x * 2 + 1) * p.C + c0 + q] = s1;
+    // thread t < 2 * G * VEC: statistic t / (G*VEC), column t % (G*VEC)   (G * VEC <= 256 / 2 except VEC 4, G 64: loop)
+    for (int t = threadIdx.x; t < 2 * G * VEC; t += kBlock) {
+        const int which = t / (G * VEC), col = t - which * (G * VEC);
+        if (col < C) {
+            double s = 0.0;
+            for (int r = 0; r < kBlock / G; ++r) s += red[which][r][col];
+            atomicAdd(slot + ((int64_t)(blockIdx.x % KPGNN_STAT_REPLICAS) * 2 + which) * C + col, s);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;   // nn.BatchNorm1d.num_batches_tracked
+    (void)c0; (void)col_ok;
 }
 
-// fwd stats: s0 = sum (x - pivot), s1 = sum (x - pivot)^2, pivot = x[0, c]
+// fwd stats: sum x, sum x^2 (fp64: no pivot needed)
 template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock) bn_stats_kernel(const BnParams p) {
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
-    float a[VEC], b[VEC], piv[VEC];
-    for (int q = 0; q < VEC; ++q) { a[q] = 0.f; b[q] = 0.f; piv[q] = 0.f; }
+    double a[VEC], b[VEC];
+    for (int q = 0; q < VEC; ++q) { a[q] = 0.0; b[q] = 0.0; }
     if (col_ok) {
-        ldv<VEC>(p.x + c0, piv);
         // four rows per trip: the loads are independent, a one-row loop keeps a single request in flight per thread
-        // (9 us for 20 MB)
         const int64_t step = (int64_t)gridDim.x * (kBlock / G);
         int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl;
         for (; r + 3 * step < p.N; r += 4 * step) {
@@ -81,63 +89,70 @@ __global__ void __launch_bounds__(kBlock) bn_stats_kernel(const BnParams p) {
             ldv<VEC>(p.x + (r + 2 * step) * p.xs + c0, v2);
             ldv<VEC>(p.x + (r + 3 * step) * p.xs + c0, v3);
             for (int q = 0; q < VEC; ++q) {
-                const float d0 = v0[q] - piv[q], d1 = v1[q] - piv[q], d2 = v2[q] - piv[q], d3 = v3[q] - piv[q];
-                a[q] += d0; b[q] = fmaf(d0, d0, b[q]);
-                a[q] += d1; b[q] = fmaf(d1, d1, b[q]);
-                a[q] += d2; b[q] = fmaf(d2, d2, b[q]);
-                a[q] += d3; b[q] = fmaf(d3, d3, b[q]);
+                a[q] += v0[q]; b[q] = fma((double)v0[q], (double)v0[q], b[q]);
+                a[q] += v1[q]; b[q] = fma((double)v1[q], (double)v1[q], b[q]);
+                a[q] += v2[q]; b[q] = fma((double)v2[q], (double)v2[q], b[q]);
+                a[q] += v3[q]; b[q] = fma((double)v3[q], (double)v3[q], b[q]);
             }
         }
         for (; r < p.N; r += step) {
             float v[VEC];
             ldv<VEC>(p.x + r * p.xs + c0, v);
-            for (int q = 0; q < VEC; ++q) { const float d = v[q] - piv[q]; a[q] += d; b[q] = fmaf(d, d, b[q]); }
+            for (int q = 0; q < VEC; ++q) { a[q] += v[q]; b[q] = fma((double)v[q], (double)v[q], b[q]); }
         }
     }
-    block_to_slab<VEC, G>(p, a, b, c0, col_ok);
+    block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
 }
 
-// fwd apply (every block recomputes mean / invstd of its columns from the reduced sums; block 0 publishes
-// them and updates the running statistics)
-template <int VEC, int G>
+// fwd apply: every block finishes mean / invstd of the columns from the slot; block 0 publishes them and updates the
+// running statistics.  OUT: the statistics of z go to out_slot (z is then the input of another BatchNorm).
+template <int VEC, int G, bool OUT>
 __global__ void __launch_bounds__(kBlock) bn_apply_kernel(const BnParams p) {
+    __shared__ float cm[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
-    if (c0 >= p.C) return;
-    float piv[VEC], mean[VEC], istd[VEC], g[VEC], bt[VEC];
-    ldv<VEC>(p.x + c0, piv);
-    ldv<VEC>(p.gamma + c0, g);
-    ldv<VEC>(p.beta + c0, bt);
-    const double inv_n = 1.0 / (double)p.N;
-    for (int q = 0; q < VEC; ++q) {
-        const double m1 = (double)p.sums[c0 + q] * inv_n;
-        double var = (double)p.sums[p.C + c0 + q] * inv_n - m1 * m1;
+    const bool col_ok = c0 < p.C;
+    for (int c = threadIdx.x; c < p.C; c += kBlock) {
+        const double inv_n = 1.0 / (double)p.N;
+        const double m1 = slot_sum(p.in_slot, p.C, 0, c) * inv_n;
+        double var = slot_sum(p.in_slot, p.C, 1, c) * inv_n - m1 * m1;
         if (var < 0.0) var = 0.0;
-        mean[q] = (float)((double)piv[q] + m1);
-        istd[q] = (float)(1.0 / sqrt(var + (double)p.eps));
-        if (blockIdx.x == 0 && rl == 0) {
-            p.mean[c0 + q] = mean[q];
-            p.invstd[c0 + q] = istd[q];
+        const float mean = (float)m1, istd = (float)(1.0 / sqrt(var + (double)p.eps));
+        cm[0][c] = mean; cm[1][c] = istd;
+        if (blockIdx.x == 0) {
+            p.mean[c] = mean; p.invstd[c] = istd;
             if (p.rmean) {
                 const double unb = p.N > 1 ? var * (double)p.N / (double)(p.N - 1) : var;
-                p.rmean[c0 + q] = (1.f - p.momentum) * p.rmean[c0 + q] + p.momentum * mean[q];
-                p.rvar[c0 + q] = (1.f - p.momentum) * p.rvar[c0 + q] + p.momentum * (float)unb;
+                p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mean;
+                p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
             }
         }
     }
-    for (int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl; r < p.N; r += (int64_t)gridDim.x * (kBlock / G)) {
-        float v[VEC], o[VEC];
-        ldv<VEC>(p.x + r * p.xs + c0, v);
-        for (int q = 0; q < VEC; ++q) {
-            o[q] = fmaf((v[q] - mean[q]) * istd[q], g[q], bt[q]);
-            if (p.relu) o[q] = fmaxf(o[q], 0.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;   // nn.BatchNorm1d.num_batches_tracked
+    __syncthreads();
+    double a[VEC], b[VEC];
+    for (int q = 0; q < VEC; ++q) { a[q] = 0.0; b[q] = 0.0; }
+    if (col_ok) {
+        float mean[VEC], istd[VEC], g[VEC], bt[VEC];
+        for (int q = 0; q < VEC; ++q) { mean[q] = cm[0][c0 + q]; istd[q] = cm[1][c0 + q]; }
+        ldv<VEC>(p.gamma + c0, g);
+        ldv<VEC>(p.beta + c0, bt);
+        for (int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl; r < p.N; r += (int64_t)gridDim.x * (kBlock / G)) {
+            float v[VEC], o[VEC];
+            ldv<VEC>(p.x + r * p.xs + c0, v);
+            for (int q = 0; q < VEC; ++q) {
+                o[q] = fmaf((v[q] - mean[q]) * istd[q], g[q], bt[q]);
+                if (p.relu) o[q] = fmaxf(o[q], 0.f);
+            }
+            if (p.res) {
+                float rr[VEC];
+                ldv<VEC>(p.res + r * p.rs + c0, rr);
+                for (int q = 0; q < VEC; ++q) o[q] += rr[q];
+            }
+            if (OUT) for (int q = 0; q < VEC; ++q) { a[q] += o[q]; b[q] = fma((double)o[q], (double)o[q], b[q]); }
+            stv<VEC>(p.z + r * p.zs + c0, o);
         }
-        if (p.res) {
-            float rr[VEC];
-            ldv<VEC>(p.res + r * p.rs + c0, rr);
-            for (int q = 0; q < VEC; ++q) o[q] += rr[q];
-        }
-        stv<VEC>(p.z + r * p.zs + c0, o);
     }
+    if (OUT) block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
 }
 
 // bwd reduce: s0 = sum dy, s1 = sum dy * xhat  (dy = dz masked by the recomputed pre-activation when relu)
@@ -145,8 +160,8 @@ template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p) {
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
-    float a[VEC], b[VEC];
-    for (int q = 0; q < VEC; ++q) { a[q] = 0.f; b[q] = 0.f; }
+    double a[VEC], b[VEC];
+    for (int q = 0; q < VEC; ++q) { a[q] = 0.0; b[q] = 0.0; }
     if (col_ok) {
         float mean[VEC], istd[VEC], g[VEC], bt[VEC];
         ldv<VEC>(p.mean + c0, mean); ldv<VEC>(p.invstd + c0, istd); ldv<VEC>(p.gamma + c0, g); ldv<VEC>(p.beta + c0, bt);
@@ -157,7 +172,7 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p)
                 const float xh = (v[q] - mean[q]) * istd[q];
                 if (p.relu && fmaf(xh, g[q], bt[q]) <= 0.f) dy[q] = 0.f;
                 a[q] += dy[q];
-                b[q] = fmaf(dy[q], xh, b[q]);
+                b[q] = fma((double)dy[q], (double)xh, b[q]);
             }
         };
         for (; r + step < p.N; r += 2 * step) {          // two rows (four independent loads) per trip
@@ -176,17 +191,23 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p)
             one(v, dy);
         }
     }
-    block_to_slab<VEC, G>(p, a, b, c0, col_ok);
+    block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
 }
 
 template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock) bn_bwd_apply_kernel(const BnParams p) {
+    __shared__ float cs[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
+    for (int c = threadIdx.x; c < p.C; c += kBlock) {
+        const float s0 = (float)slot_sum(p.in_slot, p.C, 0, c), s1 = (float)slot_sum(p.in_slot, p.C, 1, c);
+        cs[0][c] = s0; cs[1][c] = s1;
+        if (blockIdx.x == 0) { p.dbeta[c] = s0; p.dgamma[c] = s1; }
+    }
+    __syncthreads();
     if (c0 >= p.C) return;
     float mean[VEC], istd[VEC], g[VEC], bt[VEC], s0[VEC], s1[VEC];
     ldv<VEC>(p.mean + c0, mean); ldv<VEC>(p.invstd + c0, istd); ldv<VEC>(p.gamma + c0, g); ldv<VEC>(p.beta + c0, bt);
-    ldv<VEC>(p.sums + c0, s0); ldv<VEC>(p.sums + p.C + c0, s1);
-    if (blockIdx.x == 0 && rl == 0) { stv<VEC>(p.dbeta + c0, s0); stv<VEC>(p.dgamma + c0, s1); }
+    for (int q = 0; q < VEC; ++q) { s0[q] = cs[0][c0 + q]; s1[q] = cs[1][c0 + q]; }
     const float inv_n = 1.0f / (float)p.N;
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl; r < p.N; r += (int64_t)gridDim.x * (kBlock / G)) {
         float v[VEC], dy[VEC], o[VEC];
@@ -213,31 +234,22 @@ int bn_shape(int C, std::initializer_list<const void*> ptrs, std::initializer_li
     return KPGNN_OK;
 }
 
-int stream_grid(int64_t N, int G) {
+int stream_grid(int64_t N, int G, int cap_blocks) {
     const int64_t rows_per_block = kBlock / G;
     int64_t g = (N + rows_per_block * 4 - 1) / (rows_per_block * 4);   // >= 4 rows per thread
-    const int64_t cap = (int64_t)device_facts().cu_count * 8;
-    if (g > cap) g = cap;
+    if (g > cap_blocks) g = cap_blocks;
     return (int)(g < 1 ? 1 : g);
 }
 
+#define KP_BN_CASE(KERNEL, V, GG, GRID) case V * 100 + GG: hipLaunchKernelGGL((KERNEL<V, GG>), dim3(GRID), dim3(kBlock), 0, s, p); break;
 #define KP_BN_SWITCH(KERNEL, GRID)                                                                                   \
     switch (vec * 100 + g) {                                                                                         \
-        case 404: hipLaunchKernelGGL((KERNEL<4, 4>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 408: hipLaunchKernelGGL((KERNEL<4, 8>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 416: hipLaunchKernelGGL((KERNEL<4, 16>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 432: hipLaunchKernelGGL((KERNEL<4, 32>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 464: hipLaunchKernelGGL((KERNEL<4, 64>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 204: hipLaunchKernelGGL((KERNEL<2, 4>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 208: hipLaunchKernelGGL((KERNEL<2, 8>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 216: hipLaunchKernelGGL((KERNEL<2, 16>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 232: hipLaunchKernelGGL((KERNEL<2, 32>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 264: hipLaunchKernelGGL((KERNEL<2, 64>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 104: hipLaunchKernelGGL((KERNEL<1, 4>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 108: hipLaunchKernelGGL((KERNEL<1, 8>), dim3(GRID), dim3(kBlock), 0, s, p); break;                      \
-        case 116: hipLaunchKernelGGL((KERNEL<1, 16>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 132: hipLaunchKernelGGL((KERNEL<1, 32>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
-        case 164: hipLaunchKernelGGL((KERNEL<1, 64>), dim3(GRID), dim3(kBlock), 0, s, p); break;                     \
+        KP_BN_CASE(KERNEL, 4, 4, GRID) KP_BN_CASE(KERNEL, 4, 8, GRID) KP_BN_CASE(KERNEL, 4, 16, GRID)                \
+        KP_BN_CASE(KERNEL, 4, 32, GRID) KP_BN_CASE(KERNEL, 4, 64, GRID)                                              \
+        KP_BN_CASE(KERNEL, 2, 4, GRID) KP_BN_CASE(KERNEL, 2, 8, GRID) KP_BN_CASE(KERNEL, 2, 16, GRID)                \
+        KP_BN_CASE(KERNEL, 2, 32, GRID) KP_BN_CASE(KERNEL, 2, 64, GRID)                                              \
+        KP_BN_CASE(KERNEL, 1, 4, GRID) KP_BN_CASE(KERNEL, 1, 8, GRID) KP_BN_CASE(KERNEL, 1, 16, GRID)                \
+        KP_BN_CASE(KERNEL, 1, 32, GRID) KP_BN_CASE(KERNEL, 1, 64, GRID)                                              \
         default: return fail(KPGNN_EINVAL, "batch norm: no kernel for vec=%d g=%d", vec, g);                         \
     }                                                                                                                \
     KPGNN_LAUNCH_CHECK(#KERNEL)
@@ -247,17 +259,12 @@ int stream_grid(int64_t N, int G) {
 
 using namespace kpgnn;
 
-extern "C" size_t kpgnn_bn_workspace_bytes(int32_t C) {
-    if (C < 1) return 0;
-    return sizeof(float) * (size_t)(kStatBlocks + 1) * 2 * C;  // slabs + reduced sums
-}
-
 extern "C" int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "bn_fwd: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->C >= 1, "bn_fwd: bad N=%lld C=%d", (long long)d->N, d->C);
     KPGNN_REQUIRE(d->x && d->gamma && d->beta && d->mean && d->invstd && d->z, "bn_fwd: NULL pointer");
     KPGNN_REQUIRE(d->x_stride >= d->C && d->z_stride >= d->C, "bn_fwd: bad strides");
-    KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= kpgnn_bn_workspace_bytes(d->C), "bn_fwd: workspace too small");
+    KPGNN_REQUIRE(d->stat_slot != nullptr, "bn_fwd: NULL stat_slot");
     int vec, g;
     int rc = bn_shape(d->C, {d->x, d->z, d->gamma, d->beta, d->residual}, {d->x_stride, d->z_stride, d->residual ? d->r_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
@@ -265,46 +272,60 @@ extern "C" int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream) {
     p.N = d->N; p.C = d->C; p.relu = d->relu; p.eps = d->eps; p.momentum = d->momentum;
     p.x = d->x; p.xs = d->x_stride; p.gamma = d->gamma; p.beta = d->beta; p.rmean = d->running_mean; p.rvar = d->running_var;
     p.mean = d->mean; p.invstd = d->invstd; p.z = d->z; p.zs = d->z_stride; p.res = d->residual; p.rs = d->r_stride;
-    p.slab = (float*)d->workspace;
-    float* sums = p.slab + (size_t)kStatBlocks * 2 * d->C;
-    p.sums = sums;
     p.nbt = d->num_batches_tracked;
     hipStream_t s = (hipStream_t)stream;
-    int nstat = stream_grid(d->N, g);
-    if (nstat > kStatBlocks) nstat = kStatBlocks;
-    KP_BN_SWITCH(bn_stats_kernel, nstat);
-    rc = slab_reduce(p.slab, nstat, (int64_t)2 * d->C, sums, (int64_t)2 * d->C, nullptr, 0, nullptr, s);
-    if (rc != KPGNN_OK) return rc;
-    const int napply = stream_grid(d->N, g);
-    KP_BN_SWITCH(bn_apply_kernel, napply);
+    if (!d->stats_ready) {
+        p.out_slot = d->stat_slot;
+        const int nstat = stream_grid(d->N, g, kProducerBlocks);
+        KP_BN_SWITCH(bn_stats_kernel, nstat);
+    }
+    p.in_slot = d->stat_slot;
+    p.out_slot = d->out_slot;
+    if (d->out_slot) {
+        const int napply = stream_grid(d->N, g, kProducerBlocks);
+        switch (vec * 100 + g) {
+#define KP_C(V, GG) case V * 100 + GG: hipLaunchKernelGGL((bn_apply_kernel<V, GG, true>), dim3(napply), dim3(kBlock), 0, s, p); break;
+            KP_C(4, 4) KP_C(4, 8) KP_C(4, 16) KP_C(4, 32) KP_C(4, 64) KP_C(2, 4) KP_C(2, 8) KP_C(2, 16) KP_C(2, 32) KP_C(2, 64)
+            KP_C(1, 4) KP_C(1, 8) KP_C(1, 16) KP_C(1, 32) KP_C(1, 64)
+#undef KP_C
+            default: return fail(KPGNN_EINVAL, "batch norm: no kernel for vec=%d g=%d", vec, g);
+        }
+    } else {
+        const int napply = stream_grid(d->N, g, device_facts().cu_count * 8);
+        switch (vec * 100 + g) {
+#define KP_C(V, GG) case V * 100 + GG: hipLaunchKernelGGL((bn_apply_kernel<V, GG, false>), dim3(napply), dim3(kBlock), 0, s, p); break;
+            KP_C(4, 4) KP_C(4, 8) KP_C(4, 16) KP_C(4, 32) KP_C(4, 64) KP_C(2, 4) KP_C(2, 8) KP_C(2, 16) KP_C(2, 32) KP_C(2, 64)
+            KP_C(1, 4) KP_C(1, 8) KP_C(1, 16) KP_C(1, 32) KP_C(1, 64)
+#undef KP_C
+            default: return fail(KPGNN_EINVAL, "batch norm: no kernel for vec=%d g=%d", vec, g);
+        }
+    }
+    KPGNN_LAUNCH_CHECK("bn_apply_kernel");
     return KPGNN_OK;
 }
 
 extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "bn_bwd: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->C >= 1, "bn_bwd: bad N=%lld C=%d", (long long)d->N, d->C);
-    KPGNN_REQUIRE(d->x && d->dz && d->gamma && d->beta && d->mean && d->invstd && d->dx && d->dgamma && d->dbeta, "bn_bwd: NULL pointer");
-    KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= kpgnn_bn_workspace_bytes(d->C), "bn_bwd: workspace too small");
+    KPGNN_REQUIRE(d->x && d->dz && d->gamma && d->beta && d->mean && d->invstd, "bn_bwd: NULL pointer");
+    KPGNN_REQUIRE(d->reduce_only || (d->dx && d->dgamma && d->dbeta), "bn_bwd: NULL output");
+    KPGNN_REQUIRE(d->stat_slot != nullptr, "bn_bwd: NULL stat_slot");
     int vec, g;
     int rc = bn_shape(d->C, {d->x, d->dz, d->dx, d->gamma, d->beta, d->mean, d->invstd, d->dgamma, d->dbeta},
-                      {d->x_stride, d->dz_stride, d->dx_stride}, &vec, &g);
+                      {d->x_stride, d->dz_stride, d->dx ? d->dx_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
     BnParams p = {};
     p.N = d->N; p.C = d->C; p.relu = d->relu;
     p.x = d->x; p.xs = d->x_stride; p.dz = d->dz; p.dzs = d->dz_stride; p.gamma = d->gamma; p.beta = d->beta;
     p.mean = const_cast<float*>(d->mean); p.invstd = const_cast<float*>(d->invstd);
     p.z = d->dx; p.zs = d->dx_stride; p.dgamma = d->dgamma; p.dbeta = d->dbeta;
-    p.slab = (float*)d->workspace;
-    float* sums = p.slab + (size_t)kStatBlocks * 2 * d->C;
-    p.sums = sums;
-    p.nbt = nullptr;
+    p.out_slot = d->stat_slot;
+    p.in_slot = d->stat_slot;
     hipStream_t s = (hipStream_t)stream;
-    int nstat = stream_grid(d->N, g);
-    if (nstat > kStatBlocks) nstat = kStatBlocks;
+    const int nstat = stream_grid(d->N, g, kProducerBlocks);
     KP_BN_SWITCH(bn_bwd_reduce_kernel, nstat);
-    rc = slab_reduce(p.slab, nstat, (int64_t)2 * d->C, sums, (int64_t)2 * d->C, nullptr, 0, nullptr, s);
-    if (rc != KPGNN_OK) return rc;
-    const int napply = stream_grid(d->N, g);
+    if (d->reduce_only) return KPGNN_OK;
+    const int napply = stream_grid(d->N, g, device_facts().cu_count * 8);
     KP_BN_SWITCH(bn_bwd_apply_kernel, napply);
     return KPGNN_OK;
 }

@@ -20,12 +20,16 @@ struct WgParams {
     int64_t N; int O, I;
     const float* dy; int64_t dys;
     const float* x; int64_t xs;
-    float* slab;   // [gridDim.x][O*I + O]
+    const float* xm; const float* xi; const float* xg; const float* xb; int xrelu;   // optional BatchNorm(+ReLU) of x on load
+    float* slab;   // [gridDim.x][slab_row]; this problem's strip starts at slab_off
+    int64_t slab_row, slab_off;
 };
+struct WgPair { WgParams q[2]; };
 
 template <int TI>
 __global__ void __launch_bounds__(512)
-wgrad_kernel(const WgParams p) {
+wgrad_kernel(const WgPair pp) {
+    const WgParams& p = pp.q[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kk = lane >> 5, c = lane & 31;
     const int o = wave * 32 + c;                 // this lane's dy column
@@ -35,6 +39,15 @@ wgrad_kernel(const WgParams p) {
     for (int t = 0; t < TI; ++t)
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     float bsum = 0.f;
+    float tm[TI], ts[TI], tg[TI], tb[TI];        // per-lane columns i = t*32 + c: fixed for the whole launch
+    if (p.xm) {
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const int i = t * 32 + c;
+            const bool ok = i < p.I;
+            tm[t] = ok ? p.xm[i] : 0.f; ts[t] = ok ? p.xi[i] : 0.f; tg[t] = ok ? p.xg[i] : 0.f; tb[t] = ok ? p.xb[i] : 0.f;
+        }
+    }
     // rows of this block: pairs (r, r+1); block b takes pairs b, b+grid, ...
     const int64_t pairs = (p.N + 1) / 2;
     constexpr int UN = 4;
@@ -51,6 +64,18 @@ wgrad_kernel(const WgParams p) {
                 b[u][t] = (r_ok && i < p.I) ? p.x[r * p.xs + i] : 0.f;
             }
         }
+        if (p.xm) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const bool r_ok = 2 * (pr + (int64_t)u * gridDim.x) + kk < p.N;
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
+                    if (p.xrelu) v = fmaxf(v, 0.f);
+                    b[u][t] = (r_ok && t * 32 + c < p.I) ? v : 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             bsum += a[u];
@@ -59,7 +84,7 @@ wgrad_kernel(const WgParams p) {
         }
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* out = p.slab + (int64_t)blockIdx.x * ((int64_t)p.O * p.I + p.O);
+    float* out = p.slab + (int64_t)blockIdx.x * p.slab_row + p.slab_off;
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
         const int i = t * 32 + c;
@@ -70,6 +95,40 @@ wgrad_kernel(const WgParams p) {
     }
     bsum += __shfl_xor(bsum, 32);                // the two k halves hold different rows of the same column
     if (kk == 0 && o_ok) out[(int64_t)p.O * p.I + o] = bsum;
+}
+
+int wgrad_check(const kpgnn_wgrad_desc* d, const char* who) {
+    KPGNN_REQUIRE(d != nullptr, "%s: NULL descriptor", who);
+    KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "%s: bad N=%lld O=%d I=%d", who, (long long)d->N, d->O, d->I);
+    if (d->O > 256 || d->I > 256) return fail(KPGNN_ELIMIT, "%s: O=%d, I=%d exceed 256", who, d->O, d->I);
+    KPGNN_REQUIRE(d->dy && d->x && d->dw && d->dy_stride >= d->O && d->x_stride >= d->I, "%s: bad pointers/strides", who);
+    KPGNN_REQUIRE(!d->x_mean || (d->x_invstd && d->x_gamma && d->x_beta), "%s: x transform needs mean, invstd, gamma, beta", who);
+    return KPGNN_OK;
+}
+
+WgParams wgrad_params(const kpgnn_wgrad_desc* d, float* slab, int64_t slab_row, int64_t slab_off) {
+    WgParams p;
+    p.N = d->N; p.O = d->O; p.I = d->I; p.dy = d->dy; p.dys = d->dy_stride; p.x = d->x; p.xs = d->x_stride;
+    p.xm = d->x_mean; p.xi = d->x_invstd; p.xg = d->x_gamma; p.xb = d->x_beta; p.xrelu = d->x_relu;
+    p.slab = slab; p.slab_row = slab_row; p.slab_off = slab_off;
+    return p;
+}
+
+int wgrad_launch(const WgPair& pp, int nprob, int O, int I, int grid, hipStream_t s) {
+    const int waves = (O + 31) / 32, ti = (I + 31) / 32;
+    dim3 blk(waves * 64), gr(grid, nprob);
+    switch (ti) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, gr, blk, 0, s, pp); break;
+        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, gr, blk, 0, s, pp); break;
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, gr, blk, 0, s, pp); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, gr, blk, 0, s, pp); break;
+        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, gr, blk, 0, s, pp); break;
+        case 6: hipLaunchKernelGGL(wgrad_kernel<6>, gr, blk, 0, s, pp); break;
+        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, gr, blk, 0, s, pp); break;
+        default: hipLaunchKernelGGL(wgrad_kernel<8>, gr, blk, 0, s, pp); break;
+    }
+    KPGNN_LAUNCH_CHECK("wgrad_kernel");
+    return KPGNN_OK;
 }
 
 }  // namespace
@@ -83,33 +142,41 @@ extern "C" size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I) {
 }
 
 extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream) {
-    KPGNN_REQUIRE(d != nullptr, "linear_wgrad: NULL descriptor");
-    KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_wgrad: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
-    if (d->O > 256 || d->I > 256) return fail(KPGNN_ELIMIT, "linear_wgrad: O=%d, I=%d exceed 256", d->O, d->I);
-    KPGNN_REQUIRE(d->dy && d->x && d->dw && d->dy_stride >= d->O && d->x_stride >= d->I, "linear_wgrad: bad pointers/strides");
+    int rc = wgrad_check(d, "linear_wgrad");
+    if (rc != KPGNN_OK) return rc;
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= kpgnn_wgrad_workspace_bytes(d->O, d->I), "linear_wgrad: workspace too small");
-    WgParams p;
-    p.N = d->N; p.O = d->O; p.I = d->I; p.dy = d->dy; p.dys = d->dy_stride; p.x = d->x; p.xs = d->x_stride;
-    p.slab = (float*)d->workspace;
-    const int waves = (d->O + 31) / 32, ti = (d->I + 31) / 32;
-    int64_t pairs = (d->N + 1) / 2;
-    int grid = (int)(pairs < kWgradBlocks ? pairs : kWgradBlocks);
-    hipStream_t s = (hipStream_t)stream;
-    dim3 blk(waves * 64);
-    switch (ti) {
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, dim3(grid), blk, 0, s, p); break;
-        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, dim3(grid), blk, 0, s, p); break;
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, dim3(grid), blk, 0, s, p); break;
-        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, dim3(grid), blk, 0, s, p); break;
-        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, dim3(grid), blk, 0, s, p); break;
-        case 6: hipLaunchKernelGGL(wgrad_kernel<6>, dim3(grid), blk, 0, s, p); break;
-        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, dim3(grid), blk, 0, s, p); break;
-        default: hipLaunchKernelGGL(wgrad_kernel<8>, dim3(grid), blk, 0, s, p); break;
-    }
-    KPGNN_LAUNCH_CHECK("wgrad_kernel");
     const int64_t nw = (int64_t)d->O * d->I;
-    float* db = d->db ? d->db : p.slab + (size_t)kWgradBlocks * (nw + d->O);  // sink behind the slabs
-    return slab_reduce(p.slab, grid, nw + d->O, d->dw, nw, db, d->O, nullptr, s);
+    float* slab = (float*)d->workspace;
+    WgPair pp;
+    pp.q[0] = pp.q[1] = wgrad_params(d, slab, nw + d->O, 0);
+    const int64_t pairs = (d->N + 1) / 2;
+    const int grid = (int)(pairs < kWgradBlocks ? pairs : kWgradBlocks);
+    hipStream_t s = (hipStream_t)stream;
+    rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
+    if (rc != KPGNN_OK) return rc;
+    float* db = d->db ? d->db : slab + (size_t)kWgradBlocks * (nw + d->O);  // sink behind the slabs
+    return slab_reduce(slab, grid, nw + d->O, d->dw, nw, db, d->O, nullptr, s);
+}
+
+extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wgrad_desc* b, kpgnn_stream_t stream) {
+    int rc = wgrad_check(a, "linear_wgrad_pair");
+    if (rc != KPGNN_OK) return rc;
+    rc = wgrad_check(b, "linear_wgrad_pair");
+    if (rc != KPGNN_OK) return rc;
+    KPGNN_REQUIRE(a->O == b->O && a->I == b->I && a->N == b->N, "linear_wgrad_pair: the two problems must share N, O, I");
+    KPGNN_REQUIRE(a->db && b->db, "linear_wgrad_pair: both bias gradients are required");
+    KPGNN_REQUIRE(a->workspace && a->workspace_bytes >= 2 * kpgnn_wgrad_workspace_bytes(a->O, a->I), "linear_wgrad_pair: workspace too small");
+    const int64_t nw = (int64_t)a->O * a->I, one = nw + a->O;
+    float* slab = (float*)a->workspace;
+    WgPair pp;
+    pp.q[0] = wgrad_params(a, slab, 2 * one, 0);
+    pp.q[1] = wgrad_params(b, slab, 2 * one, one);
+    const int64_t pairs = (a->N + 1) / 2;
+    const int grid = (int)(pairs < kWgradBlocks / 2 ? pairs : kWgradBlocks / 2);   // two problems share the chip
+    hipStream_t s = (hipStream_t)stream;
+    rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
+    if (rc != KPGNN_OK) return rc;
+    return slab_reduce(slab, grid, 2 * one, a->dw, nw, a->db, a->O, b->dw, s, nw, b->db);
 }
 
 // ------------------------------------------------------------------------------------------------ y = x W^T + b
@@ -122,134 +189,6 @@ struct LinParams {
     const float* w; const float* bias;
     float* y; int64_t ys;
 };
-
-constexpr int kLinMaxPF = 12;    // float4 registers per thread of the prefetched x tile (up to 96 x 128 floats)
-
-// y^T tile = W_strip (A operand, registers) x x_tile^T (B operand, LDS): wave w owns outputs [32w, 32w+32) for the
-// whole launch (KS k-steps of 2 = its strip of W in KS VGPRs); a block streams tiles of 32*M rows of x through LDS
-// (odd pitch: conflict-free transposed operand reads; the next tile travels in registers meanwhile); each wave runs M
-// independent v_mfma_f32_32x32x2_f32 chains (one per 32-row group) per k-step, and the result leaves through the same
-// LDS buffer as whole rows (coalesced 16-B stores).  M is chosen so that the launch is ONE round of tiles over two
-// blocks per CU (N = 47k: 96-row tiles, 495 blocks).  wt = 1 reads the weight transposed (w[k][o]): the same kernel
-// gives dx = dy W without a transposed copy.
-template <int KS, int M>
-__global__ void __launch_bounds__(256, 2)
-linear_fwd_kernel(const LinParams p) {
-    extern __shared__ __attribute__((aligned(16))) float xl[];      // [32*M][pitch]
-    constexpr int ROWS = 32 * M;
-    constexpr int PF = (M * 32 * 128 / 4 + 255) / 256 > kLinMaxPF ? kLinMaxPF : (M * 32 * 128 / 4 + 255) / 256;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int kk = lane >> 5, c = lane & 31;
-    const int I = p.I, O = p.O, pitch = p.pitch;
-    const int o = wave * 32 + c;
-    // this wave's strip of the weight as MFMA A-fragments: a[ks] = W[o][2 ks + kk]
-    float a[KS];
-    if (p.wt) {                                       // w is [I][O]: lanes run along o, coalesced as is
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = o < O ? p.w[(int64_t)(2 * ks + kk) * O + o] : 0.f;
-    } else {                                          // w is [O][I]: every lane streams ITS row 16 B at a time (the two
-#pragma unroll                                        // k-halves share the loads) instead of 2*KS strided dword loads
-        for (int j = 0; j < KS / 2; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o < O) v = *reinterpret_cast<const float4*>(p.w + (int64_t)o * I + 4 * j);
-            a[2 * j] = kk ? v.y : v.x;
-            a[2 * j + 1] = kk ? v.w : v.z;
-        }
-    }
-    const int64_t tiles = (p.N + ROWS - 1) / ROWS;
-    constexpr int IC = 2 * KS;                        // == I (host): compile-time divisor
-    int lo[PF];                                       // LDS offset of this thread's q-th float4 (tile independent)
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-        const int e = 4 * (tid + q * 256);
-        lo[q] = e < ROWS * IC ? (e / IC) * pitch + (e % IC) : -1;
-    }
-    const int yp = p.ypitch;
-    int yo[PF];                                       // LDS offset of the q-th float4 of the y tile (one division, then steps)
-    {
-        const int step_r = 1024 / O, step_c = 1024 - step_r * O;
-        int r = (4 * tid) / O, cc = 4 * tid - r * O;
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            yo[q] = r < ROWS ? r * yp + cc : 0;
-            r += step_r; cc += step_c;
-            if (cc >= O) { cc -= O; ++r; }
-        }
-    }
-    float4 pf[PF];
-    auto issue = [&](int64_t tl) {
-        const int64_t r0 = tl * ROWS;
-        const int64_t lim = (p.N - r0 < ROWS ? p.N - r0 : ROWS) * (int64_t)I;
-        const float* base = p.x + r0 * p.xs;          // xs == I (host): a tile is one contiguous run
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int e = 4 * (tid + q * 256);
-            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < lim) pf[q] = *reinterpret_cast<const float4*>(base + e);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int q = 0; q < PF; ++q)
-            if (lo[q] >= 0) *reinterpret_cast<float4*>(xl + lo[q]) = pf[q];
-    };
-    int64_t tile = blockIdx.x;
-    if (tile < tiles) { issue(tile); commit(); }
-    __syncthreads();
-    for (; tile < tiles; tile += gridDim.x) {
-        const bool more = tile + gridDim.x < tiles;
-        if (more) issue(tile + gridDim.x);
-        f32x16 acc[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-            for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
-        const float* b0 = xl + c * pitch + kk;
-        // I == 2 * KS exactly (host): plain LDS reads the scheduler can hoist ahead of the MFMAs (a per-lane predicate
-        // on the read made every MFMA wait for its own ds_read: 31 us instead of ~13)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float xv = b0[m * 32 * pitch + 2 * ks];
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xv, acc[m], 0, 0, 0);
-            }
-        }
-        __syncthreads();                               // every wave is done reading the x tile: it becomes the y tile
-        {
-        // C/D map: col = lane & 31 (tile row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output o)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ob = wave * 32 + 8 * g + 4 * kk;
-            if (ob < O) {                              // O % 4 == 0 (host): the 4 outputs of a group are in or out together
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + ob);
-#pragma unroll
-                for (int m = 0; m < M; ++m)            // y view: pitch = 4 (mod 8) floats -> 16-B LDS accesses, no conflicts
-                    *reinterpret_cast<float4*>(xl + (m * 32 + c) * yp + ob) =
-                        make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
-            }
-        }
-        __syncthreads();
-        {
-            const int64_t r0 = tile * ROWS;
-            const int rows = (int)(p.N - r0 < ROWS ? p.N - r0 : ROWS);
-            float* ybase = p.y + r0 * p.ys;            // ys == O (host): whole rows, contiguous
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = 4 * (tid + q * 256);
-                if (e < rows * O) *reinterpret_cast<float4*>(ybase + e) = *reinterpret_cast<const float4*>(xl + yo[q]);
-            }
-            for (int e = 4 * (tid + PF * 256); e < rows * O; e += 4 * 256) {
-                const int r = e / O, oo = e - r * O;
-                *reinterpret_cast<float4*>(ybase + e) = *reinterpret_cast<const float4*>(xl + r * yp + oo);
-            }
-        }
-        }
-        __syncthreads();                               // the y tile is out: the buffer takes the next x tile
-        if (more) commit();
-        __syncthreads();
-    }
-}
 
 // Wide outputs (O > 128, e.g. the input gradient of the jumping-knowledge projection: [N,104] x [104,936]): the x tile
 // stays resident in LDS while the block walks the outputs 128 at a time - per chunk every wave reloads its strip of the
@@ -343,14 +282,17 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     if ((d->O % 4) != 0 || (d->I % 4) != 0 || d->x_stride != d->I || d->y_stride != d->O ||
         (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
         return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->O <= 128) {                                  // the plain variant of the fused kernel (lin_fused.h)
+        kpgnn_linear_bn_desc f = {};
+        f.N = d->N; f.O = d->O; f.I = d->I; f.x = d->x; f.w = d->w; f.bias = d->bias; f.y = d->y; f.w_transposed = d->w_transposed;
+        return kpgnn_linear_bn(&f, stream);
+    }
+    if (d->I != 32 && d->I != 64 && d->I != 104 && d->I != 128)
+        return fail(KPGNN_ELIMIT, "linear_fwd: wide outputs need I in {32, 64, 104, 128} (the k-loop is fully unrolled)");
     LinParams p;
     p.N = d->N; p.O = d->O; p.I = d->I; p.wt = d->w_transposed ? 1 : 0;
-    // one pitch = 4 (mod 8) floats for the x and the y view of the buffer: 16-B aligned rows (the tile is committed and
-    // drained with b128 LDS accesses); the transposed operand reads then see a 2-way bank conflict, which hides behind
-    // the 64-cycle MFMAs
-    const bool wide = d->O > 128;
-    const int wmax = (wide || d->I > d->O) ? d->I : d->O;
-    const int rowp = wmax + ((4 - wmax % 8) + 8) % 8;
+    const int rowp = d->I + ((4 - d->I % 8) + 8) % 8;   // pitch = 4 (mod 8) floats: 16-B aligned rows, conflict-free 16-B accesses
     p.pitch = rowp; p.ypitch = rowp;
     p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
     // rows per tile = 32 * m, m in 1..3, the smallest that makes the launch one round over two blocks per CU
@@ -360,24 +302,19 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const int rows = 32 * m;
     const size_t lds = sizeof(float) * (size_t)rows * rowp;
     const int64_t tiles = (d->N + rows - 1) / rows;
-    int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
-    hipStream_t s = (hipStream_t)stream;
+    const int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
     dim3 blk(256);
     const int ks = (d->I + 1) / 2;
-#define KP_LIN2(KSV, MV) do { if (wide) { \
+#define KP_LIN2(KSV, MV) do { \
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_wide_kernel<KSV, MV>, lds)); \
-        hipLaunchKernelGGL((linear_wide_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); \
-    } else { \
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_fwd_kernel<KSV, MV>, lds)); \
-        hipLaunchKernelGGL((linear_fwd_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } } while (0)
+        hipLaunchKernelGGL((linear_wide_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } while (0)
 #define KP_LIN(KSV) do { if (m == 1) KP_LIN2(KSV, 1); else if (m == 2) KP_LIN2(KSV, 2); else KP_LIN2(KSV, 3); } while (0)
     if (ks == 16) KP_LIN(16);
     else if (ks == 32) KP_LIN(32);
     else if (ks == 52) KP_LIN(52);
-    else if (ks == 64) KP_LIN(64);
-    else return fail(KPGNN_ELIMIT, "linear_fwd: I=%d is not one of 32, 64, 104, 128 (the k-loop is fully unrolled)", d->I);
+    else KP_LIN(64);
 #undef KP_LIN
 #undef KP_LIN2
-    KPGNN_LAUNCH_CHECK("linear_fwd_kernel");
+    KPGNN_LAUNCH_CHECK("linear_wide_kernel");
     return KPGNN_OK;
 }

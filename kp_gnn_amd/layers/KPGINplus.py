@@ -57,4 +57,5 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
             xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
                                 xbias=xbias, share_slot_grads=_history)                       # N,k,H
             h = self.combine(xn)
-        return mlp_linear_bn_relu_x2(self.mlp, h)
+        # (_kp_emit_out_stats: set by a caller that applies a BatchNorm to the result next - kp_gnn_amd.body does)
+        return mlp_linear_bn_relu_x2(self.mlp, h, emit_out_stats=getattr(self, "_kp_emit_out_stats", False))

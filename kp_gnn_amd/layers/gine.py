@@ -40,4 +40,4 @@ class GINEConv(KHopMessagePassing):
         csr, k_act = get_khop_csr(edge_index, edge_attr, n)
         out = khop_aggregate(x.reshape(n, 1, self.input_size), csr, k_act, MODE_GIN,
                              table0=self.hop1_edge_emb.weight, eps=self.eps)
-        return mlp_linear_bn_relu_x2(self.mlp, out.squeeze())
+        return mlp_linear_bn_relu_x2(self.mlp, out.squeeze(1), emit_out_stats=getattr(self, "_kp_emit_out_stats", False))

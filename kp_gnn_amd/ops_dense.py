@@ -11,30 +11,84 @@ from . import _lib
 from .ops import _ptr, _stream
 
 
-_bn_ws = {}
+# ------------------------------------------------------------------------------------------- column-statistics slots
+STAT_REPLICAS = 8          # KPGNN_STAT_REPLICAS (include/kpgnn.h)
+_EAGER_DOUBLES = 1 << 20   # 8 MB of slots between two zero fills when launching eagerly
+_GRAPH_DOUBLES = 1 << 18   # 2 MB per captured graph (zero-filled by a node of the graph itself at every replay)
 
 
-def _bn_workspace(lib, dev, C):
-    """Persistent per-(device, C) scratch for the partial sums (no allocator round trip per call).  BatchNorm launches
-    of one device are stream-ordered (one compute stream, or one captured graph), so they can share it."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), C)
-    ent = _bn_ws.get(key)
-    if ent is None:
-        nb = int(lib.kpgnn_bn_workspace_bytes(C))
-        ent = _bn_ws[key] = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
-    return ent
+class _Arena:
+    __slots__ = ("buf", "off")
+
+    def __init__(self, n, dev):
+        self.buf = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.off = 0
+
+
+_arenas = {}   # device index -> {"eager": _Arena, "cap_id": int, "cap": _Arena}
+
+
+def take_stat_slot(C, dev):
+    """A zeroed column-statistics slot (double[STAT_REPLICAS][2][C], include/kpgnn.h) for ONE producer launch + ONE
+    consumer launch.  Slots come from a per-device arena and are never handed out twice between two zero fills of the
+    arena, so no per-use memset exists: eagerly the arena is re-zeroed every ~600 slots; a hipGraph capture gets an
+    arena of its own, allocated and zero-filled INSIDE the capture (the fill is a node of the graph: every replay
+    starts from zeros, and the memory lives in the graph's pool).
+    Callers take every slot of an operator before they launch its first kernel (a wrap-around fill must not land
+    between a slot's producer and its consumer)."""
+    lib = _lib.load()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _arenas.get(idx)
+    if st is None:
+        st = _arenas[idx] = {"eager": None, "cap_id": 0, "cap": None}
+    cid = ctypes.c_uint64(0)
+    _lib.check(lib.kpgnn_stream_capture_id(torch.cuda.current_stream(dev).cuda_stream, ctypes.byref(cid)), "kpgnn_stream_capture_id")
+    if cid.value == 0:
+        if st["eager"] is None:
+            st["eager"] = _Arena(_EAGER_DOUBLES, dev)
+        a = st["eager"]
+    else:
+        if st["cap_id"] != cid.value or st["cap"] is None:
+            st["cap"], st["cap_id"] = _Arena(_GRAPH_DOUBLES, dev), cid.value
+        a = st["cap"]
+    n = (STAT_REPLICAS * 2 * C + 31) // 32 * 32
+    if a.off + n > a.buf.numel():
+        a.buf.zero_()
+        a.off = 0
+    v = a.buf[a.off:a.off + n]
+    a.off += n
+    return v
+
+
+_COLSTATS = "_kpgnn_colstats"
+
+
+def attach_column_stats(t, slot):
+    """Mark `t` as carrying its column statistics (sum, sum of squares) in `slot`: a following batch_norm_act skips its
+    stats pass.  Valid for this tensor object at this version only."""
+    try:
+        setattr(t, _COLSTATS, (t._version, slot))
+    except Exception:  # pragma: no cover
+        pass
+
+
+def _column_stats_of(t):
+    rec = getattr(t, _COLSTATS, None)
+    if rec is not None and rec[0] == t._version:
+        return rec[1]
+    return None
 
 
 class BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None, ready_slot=None):
         lib = _lib.load()
         x = x if x.stride(-1) == 1 else x.contiguous()
         N, C = x.shape
         dev = x.device
+        slot = ready_slot if ready_slot is not None else take_stat_slot(C, dev)
         z = torch.empty((N, C), dtype=torch.float32, device=dev)
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
-        ws, ws_bytes = _bn_workspace(lib, dev, C)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
         d.x, d.x_stride = x.data_ptr(), x.stride(0)
@@ -45,7 +99,7 @@ class BatchNormAct(torch.autograd.Function):
         if residual is not None:
             residual = residual if residual.stride(-1) == 1 else residual.contiguous()
             d.residual, d.r_stride = residual.data_ptr(), residual.stride(0)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+        d.stat_slot, d.stats_ready = slot.data_ptr(), 1 if ready_slot is not None else 0
         d.num_batches_tracked = _ptr(nbt)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_fwd")
@@ -61,20 +115,22 @@ class BatchNormAct(torch.autograd.Function):
         dz = dz if dz.stride(-1) == 1 else dz.contiguous()
         N, C = x.shape
         dev = x.device
+        slot = take_stat_slot(C, dev)
         dx = torch.empty((N, C), dtype=torch.float32, device=dev)
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
-        ws, ws_bytes = _bn_workspace(lib, dev, C)
         d = _lib.BnBwdDesc()
         d.N, d.C, d.relu = N, C, 1 if ctx.relu else 0
         d.x, d.x_stride, d.dz, d.dz_stride = x.data_ptr(), x.stride(0), dz.data_ptr(), dz.stride(0)
         d.gamma, d.beta, d.mean, d.invstd = gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
         d.dx, d.dx_stride = dx.data_ptr(), dx.stride(0)
         d.dgamma, d.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
-        d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+        d.stat_slot = slot.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_bwd")
-        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None, None, None
 
+
+_LIN_WIDTHS = (32, 64, 96, 104, 128)   # lin_fused.h: fully unrolled k-loops
 
 # kpgnn_linear_fwd: y = x W^T + b and dx = dy W for tall-skinny x on the fp32 matrix cores.  Measured 21.8 us per
 # [47k,104] x [104,104] launch against 29 us for the BLAS library's kernel (profiles/r01): on by default for the shapes
@@ -89,7 +145,7 @@ def _mfma_linear(x, w, bias, transposed=False):
     lib = _lib.load()
     N, I = x.shape
     O = w.shape[1] if transposed else w.shape[0]
-    if (O % 4 != 0 or I not in (32, 64, 104, 128) or O > 4096 or N < 1024 or not x.is_contiguous()
+    if (O % 4 != 0 or I not in _LIN_WIDTHS or (O > 128 and I == 96) or O > 4096 or N < 1024 or not x.is_contiguous()
             or not w.is_contiguous() or x.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 16)):
         return None
     y = torch.empty((N, O), dtype=torch.float32, device=x.device)
@@ -162,7 +218,8 @@ def batch_norm_act(x, bn, relu=False, residual=None):
     if use_hip:
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
         nbt = bn.num_batches_tracked if bn.track_running_stats else None   # incremented inside the stats kernel
-        return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt)
+        return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt,
+                                  _column_stats_of(x))
     out = bn(x)
     if relu:
         out = F.relu(out)
@@ -171,9 +228,131 @@ def batch_norm_act(x, bn, relu=False, residual=None):
     return out
 
 
-def mlp_linear_bn_relu_x2(mlp, h):
-    """nn.Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) (KPGINplus.py:25-30, gine.py:31-38):
-    the two GEMMs go to hipBLASLt, each BatchNorm+ReLU pair is one fused stats/apply on the HIP kernels."""
+def _lin_bn(lib, dev, **kw):
+    d = _lib.LinearBnDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
+    with torch.cuda.device(dev):
+        _lib.check(lib.kpgnn_linear_bn(ctypes.byref(d), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_linear_bn")
+
+
+class FusedMLP(torch.autograd.Function):
+    """z = relu(bn2(relu(bn1(h W0^T + b0)) W3^T + b3)), training mode, as 3 launches forward and 5 backward
+    (kpgnn_linear_bn / kpgnn_bn_fwd / kpgnn_bn_bwd / kpgnn_linear_wgrad_pair around column-statistics slots):
+      fwd  y1 = h W0^T + b0 (+ column sums of y1) | y2 = relu(bn1(y1)) W3^T + b3 (bn1 applied while the tile loads; + sums
+           of y2) | z = relu(bn2(y2)) (+ sums of z for the caller's next BatchNorm, when asked)
+      bwd  bn2 reduce | dy2 = bn2'(dz) on load, da1 = dy2 W3 masked by relu1, bn1 reduce in the epilogue | dy1 = bn1'(da1)
+           on load, dh = dy1 W0 | both weight gradients in one launch (relu(bn1(y1)) recomputed on load) + one reduce.
+    The activations a1 = relu(bn1(y1)) are never written to memory."""
+
+    @staticmethod
+    def forward(ctx, h, w0, b0, g1, be1, w3, b3, g2, be2, bn1, bn2, out_slot):
+        lib = _lib.load()
+        dev = h.device
+        N, I = h.shape
+        O = w0.shape[0]
+        h = h.contiguous()
+        w0c, w3c = w0.contiguous(), w3.contiguous()
+        slot1, slot2 = take_stat_slot(O, dev), take_stat_slot(O, dev)
+        y1 = torch.empty((N, O), dtype=torch.float32, device=dev)
+        y2 = torch.empty((N, O), dtype=torch.float32, device=dev)
+        z = torch.empty((N, O), dtype=torch.float32, device=dev)
+        st = torch.empty((4, O), dtype=torch.float32, device=dev)      # mean1, invstd1, mean2, invstd2
+        _lin_bn(lib, dev, N=N, O=O, I=I, x=h, w=w0c, bias=b0, y=y1, pro=0, epi=1, out_slot=slot1)
+        track1 = bn1.track_running_stats
+        _lin_bn(lib, dev, N=N, O=O, I=O, x=y1, w=w3c, bias=b3, y=y2, pro=1, epi=1, pro_relu=1, in_slot=slot1, in_gamma=g1,
+                in_beta=be1, in_eps=float(bn1.eps), momentum=float(bn1.momentum), in_mean=st[0], in_invstd=st[1],
+                running_mean=bn1.running_mean if track1 else None, running_var=bn1.running_var if track1 else None,
+                num_batches_tracked=bn1.num_batches_tracked if track1 else None, out_slot=slot2)
+        d = _lib.BnDesc()
+        d.N, d.C, d.relu, d.eps, d.momentum = N, O, 1, float(bn2.eps), float(bn2.momentum)
+        d.x, d.x_stride, d.gamma, d.beta = y2.data_ptr(), O, g2.data_ptr(), be2.data_ptr()
+        if bn2.track_running_stats:
+            d.running_mean, d.running_var = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
+            d.num_batches_tracked = bn2.num_batches_tracked.data_ptr()
+        d.mean, d.invstd, d.z, d.z_stride = st[2].data_ptr(), st[3].data_ptr(), z.data_ptr(), O
+        d.stat_slot, d.stats_ready, d.out_slot = slot2.data_ptr(), 1, _ptr(out_slot)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_fwd")
+        ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st)
+        ctx.has_b0, ctx.has_b3 = b0 is not None, b3 is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        h, w0, w3, g1, be1, g2, be2, y1, y2, st = ctx.saved_tensors
+        lib = _lib.load()
+        dev = h.device
+        N, I = h.shape
+        O = w0.shape[0]
+        dz = dz.contiguous()
+        slot2, slot1 = take_stat_slot(O, dev), take_stat_slot(O, dev)
+        dy2 = torch.empty((N, O), dtype=torch.float32, device=dev)
+        da1 = torch.empty((N, O), dtype=torch.float32, device=dev)
+        dy1 = torch.empty((N, O), dtype=torch.float32, device=dev)
+        dh = torch.empty((N, I), dtype=torch.float32, device=dev)
+        gb = torch.empty((4, O), dtype=torch.float32, device=dev)      # dgamma2, dbeta2, dgamma1, dbeta1
+        d = _lib.BnBwdDesc()
+        d.N, d.C, d.relu = N, O, 1
+        d.x, d.x_stride, d.dz, d.dz_stride = y2.data_ptr(), O, dz.data_ptr(), O
+        d.gamma, d.beta, d.mean, d.invstd = g2.data_ptr(), be2.data_ptr(), st[2].data_ptr(), st[3].data_ptr()
+        d.stat_slot, d.reduce_only = slot2.data_ptr(), 1
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_bwd")
+        _lin_bn(lib, dev, N=N, O=O, I=O, x=dz, w=w3, y=da1, w_transposed=1, pro=2, epi=2, pro_relu=1, in_slot=slot2,
+                in_gamma=g2, in_beta=be2, in_mean=st[2], in_invstd=st[3], x2=y2, xt=dy2, dgamma=gb[0], dbeta=gb[1],
+                out_slot=slot1, e_x=y1, e_mean=st[0], e_invstd=st[1], e_gamma=g1, e_beta=be1)
+        _lin_bn(lib, dev, N=N, O=I, I=O, x=da1, w=w0, y=dh, w_transposed=1, pro=2, epi=0, pro_relu=0, in_slot=slot1,
+                in_gamma=g1, in_beta=be1, in_mean=st[0], in_invstd=st[1], x2=y1, xt=dy1, dgamma=gb[2], dbeta=gb[3])
+        # weight gradients: dW3 = dy2^T relu(bn1(y1)), dW0 = dy1^T h
+        dw3 = torch.empty((O, O), dtype=torch.float32, device=dev)
+        dw0 = torch.empty((O, I), dtype=torch.float32, device=dev)
+        db = torch.empty((2, O), dtype=torch.float32, device=dev)
+        a, b = _lib.WgradDesc(), _lib.WgradDesc()
+        a.N, a.O, a.I = N, O, O
+        a.dy, a.dy_stride, a.x, a.x_stride = dy2.data_ptr(), O, y1.data_ptr(), O
+        a.dw, a.db = dw3.data_ptr(), db[0].data_ptr()
+        a.x_mean, a.x_invstd, a.x_gamma, a.x_beta, a.x_relu = st[0].data_ptr(), st[1].data_ptr(), g1.data_ptr(), be1.data_ptr(), 1
+        b.N, b.O, b.I = N, O, I
+        b.dy, b.dy_stride, b.x, b.x_stride = dy1.data_ptr(), O, h.data_ptr(), I
+        b.dw, b.db = dw0.data_ptr(), db[1].data_ptr()
+        with torch.cuda.device(dev):
+            if I == O:
+                nb = 2 * int(lib.kpgnn_wgrad_workspace_bytes(O, O))
+                ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+                _lib.check(lib.kpgnn_linear_wgrad_pair(ctypes.byref(a), ctypes.byref(b), _stream(h)), "kpgnn_linear_wgrad_pair")
+            else:
+                for q in (a, b):
+                    nb = int(lib.kpgnn_wgrad_workspace_bytes(q.O, q.I))
+                    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    q.workspace, q.workspace_bytes = ws.data_ptr(), nb
+                    _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(q), _stream(h)), "kpgnn_linear_wgrad")
+        return (dh if ctx.needs_input_grad[0] else None, dw0, db[1] if ctx.has_b0 else None, gb[2], gb[3],
+                dw3, db[0] if ctx.has_b3 else None, gb[0], gb[1], None, None, None)
+
+
+def _fusable_bn(bn):
+    return bn.training and bn.affine and bn.momentum is not None
+
+
+def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False):
+    """nn.Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) (KPGINplus.py:25-30, gine.py:31-38).
+    Training mode on covered widths: the fused 3 + 5 launch path (FusedMLP); otherwise Linear and BatchNorm one by one.
+    emit_out_stats: also accumulate the column statistics of the result and attach them to it, for a BatchNorm the
+    caller applies next (the bodies' per-layer norm)."""
+    l0, bn1, l3, bn2 = mlp[0], mlp[1], mlp[3], mlp[4]
+    O, I = l0.weight.shape
+    if (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and torch.is_grad_enabled() and _fusable_bn(bn1)
+            and _fusable_bn(bn2) and I in _LIN_WIDTHS and O in _LIN_WIDTHS and tuple(l3.weight.shape) == (O, O)
+            and h.shape[0] >= 1 and h.data_ptr() % 16 == 0
+            and (l0.bias is None or l0.bias.data_ptr() % 16 == 0) and (l3.bias is None or l3.bias.data_ptr() % 16 == 0)):
+        out_slot = take_stat_slot(O, h.device) if emit_out_stats else None
+        z = FusedMLP.apply(h, l0.weight, l0.bias, bn1.weight, bn1.bias, l3.weight, l3.bias, bn2.weight, bn2.bias, bn1, bn2,
+                           out_slot)
+        if out_slot is not None:
+            attach_column_stats(z, out_slot)
+        return z
     h = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
     return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)
 

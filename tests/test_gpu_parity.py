@@ -518,6 +518,40 @@ def test_linear_wgrad_mfma_vs_torch(N, O, I):
     _close(wd2.grad, wr.grad, "dW (no bias)", rtol=2e-4, atol=2e-5)
 
 
+def test_linear_wgrad_pair_and_x_transform():
+    """kpgnn_linear_wgrad_pair (two weight gradients, one launch + one reduce) and the BatchNorm+ReLU transform of x on
+    load, through the C ABI, against torch."""
+    import ctypes
+    from kp_gnn_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    N, O, I = 3001, 104, 104
+    dy1, dy2 = torch.randn(N, O, generator=g), torch.randn(N, O, generator=g) * (1 + 0.03 * torch.arange(O))
+    x1, x2 = torch.randn(N, I, generator=g), torch.randn(N, I, generator=g) * 2 + 1
+    mean, istd, gam, bet = (torch.randn(I, generator=g), torch.rand(I, generator=g) + 0.5, torch.randn(I, generator=g),
+                            torch.randn(I, generator=g))
+    x1t = torch.relu((x1 - mean) * istd * gam + bet)
+    T = lambda t: t.to(dev).contiguous()
+    d_dy1, d_dy2, d_x1, d_x2, d_m, d_i, d_g, d_b = map(T, (dy1, dy2, x1, x2, mean, istd, gam, bet))
+    dw = torch.empty(2, O, I, device=dev)
+    db = torch.empty(2, O, device=dev)
+    nb = 2 * int(lib.kpgnn_wgrad_workspace_bytes(O, I))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    a, b = _lib.WgradDesc(), _lib.WgradDesc()
+    for q, dy, x, k in ((a, d_dy1, d_x1, 0), (b, d_dy2, d_x2, 1)):
+        q.N, q.O, q.I = N, O, I
+        q.dy, q.dy_stride, q.x, q.x_stride = dy.data_ptr(), O, x.data_ptr(), I
+        q.dw, q.db = dw[k].data_ptr(), db[k].data_ptr()
+    a.x_mean, a.x_invstd, a.x_gamma, a.x_beta, a.x_relu = d_m.data_ptr(), d_i.data_ptr(), d_g.data_ptr(), d_b.data_ptr(), 1
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+    _lib.check(lib.kpgnn_linear_wgrad_pair(ctypes.byref(a), ctypes.byref(b), torch.cuda.current_stream().cuda_stream), "pair")
+    _close(dw[0], dy1.t() @ x1t, "dw(transformed x)", rtol=2e-4, atol=2e-5)
+    _close(dw[1], dy2.t() @ x2, "dw", rtol=2e-4, atol=2e-5)
+    _close(db[0], dy1.sum(0), "db0", rtol=2e-4, atol=2e-5)
+    _close(db[1], dy2.sum(0), "db1", rtol=2e-4, atol=2e-5)
+
+
 def test_kgin_simulation_layer_vs_oracle():
     """run_simulation.py's mask-only KGINConv on 3-regular graphs (config 4 shapes, small n): fwd + grads vs the
     oracle restatement (parity unpinned by reference execution: run_simulation.py is a script that cannot be
@@ -611,13 +645,8 @@ def test_mfma_linear_forward_kernel(N, O, I):
         dy, wd = x, torch.randn(I, O, generator=g) * 0.1
     else:
         dy, wd = torch.randn(N, O, generator=g) * (1 + 0.02 * torch.arange(O)), w
-    saved = ops_dense._USE_MFMA_LINEAR
-    ops_dense._USE_MFMA_LINEAR = True
-    try:
-        y = ops_dense._mfma_linear(x.to(dev), w.to(dev), b.to(dev))
-        dx = ops_dense._mfma_linear(dy.to(dev), wd.to(dev), None, transposed=True)
-    finally:
-        ops_dense._USE_MFMA_LINEAR = saved
+    y = ops_dense._mfma_linear(x.to(dev), w.to(dev), b.to(dev))
+    dx = ops_dense._mfma_linear(dy.to(dev), wd.to(dev), None, transposed=True)
     assert y is not None and dx is not None
     _close(y, torch.nn.functional.linear(x, w, b), "y", rtol=2e-4, atol=2e-5)
     _close(dx, dy @ wd, "dx", rtol=2e-4, atol=2e-5)
@@ -813,3 +842,105 @@ def test_embedding_rows_validates_range_and_padding():
     ref[3] = 2
     ref[6] = 1
     assert torch.equal(w.grad.cpu(), ref)            # row 0 (padding) receives nothing
+
+
+# ----------------------------------------------------------------------------- fused Linear-BatchNorm-ReLU x2 MLP
+@pytest.mark.parametrize("N,I,O", [(4099, 104, 104), (1500, 64, 104), (47450, 104, 104), (33, 32, 32), (2048, 96, 96),
+                                   (2500, 128, 128), (1000, 104, 64), (20000, 104, 104), (1, 32, 32)])
+@pytest.mark.parametrize("follow_norm", [False, True])
+def test_fused_mlp_vs_torch(N, I, O, follow_norm):
+    """kpgnn_linear_bn + slots: Linear-BN-ReLU-Linear-BN-ReLU (KPGINplus.py:25-30) in 3 + 5 launches against the same
+    nn.Sequential in torch on the CPU (training mode): output, running statistics, the input gradient and every
+    parameter gradient; follow_norm adds the bodies' next BatchNorm + residual, which takes its statistics from the
+    slot the MLP's last kernel filled (no stats pass).  Large means exercise the fp64 statistics."""
+    import copy
+    from kp_gnn_amd.ops_dense import batch_norm_act, mlp_linear_bn_relu_x2
+    if N == 1:
+        pytest.skip("BatchNorm1d in training mode needs more than one row (torch raises too)")
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + 3 * I + O)
+    ref = torch.nn.Sequential(torch.nn.Linear(I, O), torch.nn.BatchNorm1d(O), torch.nn.ReLU(),
+                              torch.nn.Linear(O, O), torch.nn.BatchNorm1d(O), torch.nn.ReLU())
+    norm_ref = torch.nn.BatchNorm1d(O)
+    with torch.no_grad():
+        for m in list(ref) + [norm_ref]:
+            for prm in m.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.3 if prm.dim() == 2 else 1.0))
+        ref[0].bias.add_(3.0)                 # large column means in front of the first BatchNorm
+    hip, norm_hip = copy.deepcopy(ref).to(dev).train(), copy.deepcopy(norm_ref).to(dev).train()
+    x = torch.randn(N, I, generator=g) * (1 + 0.02 * torch.arange(I)) + 0.5
+    res = torch.randn(N, O, generator=g)
+    w = torch.randn(N, O, generator=g)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    out = ref(xr)
+    if follow_norm:
+        out = norm_ref(out) + rr
+    (out * w).sum().backward()
+    xd, rd = x.to(dev).requires_grad_(True), res.to(dev).requires_grad_(True)
+    outd = mlp_linear_bn_relu_x2(hip, xd, emit_out_stats=follow_norm)
+    if follow_norm:
+        from kp_gnn_amd import ops_dense
+        assert ops_dense._column_stats_of(outd) is not None      # the fused path ran and left its statistics
+        outd = batch_norm_act(outd, norm_hip, relu=False, residual=rd)
+    (outd * w.to(dev)).sum().backward()
+    _close(outd, out, "out", rtol=2e-4, atol=3e-5)
+    _close(xd.grad, xr.grad, "dx", rtol=3e-4, atol=5e-5)
+    if follow_norm:
+        _close(rd.grad, rr.grad, "dres")
+    pr, ph = dict(ref.named_parameters()), dict(hip.named_parameters())
+    if follow_norm:
+        pr.update({"norm." + k: v for k, v in norm_ref.named_parameters()})
+        ph.update({"norm." + k: v for k, v in norm_hip.named_parameters()})
+    _close_param_grads(ph, {k: v.grad for k, v in pr.items()}, f"mlp{N}x{I}x{O}", 3e-4, 5e-5)
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            _close(hip.state_dict()[k], v, k, rtol=2e-4, atol=2e-5)
+        if k.endswith("num_batches_tracked"):
+            assert int(hip.state_dict()[k]) == int(v) == 1
+
+
+def test_fused_mlp_falls_back_outside_its_shapes():
+    """Widths the unrolled kernels do not cover (h = 40) and eval mode keep working through the one-by-one path."""
+    import copy
+    from kp_gnn_amd.ops_dense import mlp_linear_bn_relu_x2
+    dev = _dev()
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(40, 40), torch.nn.BatchNorm1d(40), torch.nn.ReLU(),
+                              torch.nn.Linear(40, 40), torch.nn.BatchNorm1d(40), torch.nn.ReLU())
+    hip = copy.deepcopy(ref).to(dev)
+    x = torch.randn(1500, 40)
+    _close(mlp_linear_bn_relu_x2(hip.train(), x.to(dev)), ref.train()(x), "h40 train", rtol=2e-4, atol=2e-5)
+    ref104 = torch.nn.Sequential(torch.nn.Linear(104, 104), torch.nn.BatchNorm1d(104), torch.nn.ReLU(),
+                                 torch.nn.Linear(104, 104), torch.nn.BatchNorm1d(104), torch.nn.ReLU())
+    hip104 = copy.deepcopy(ref104).to(dev)
+    x = torch.randn(1500, 104)
+    _close(mlp_linear_bn_relu_x2(hip104.eval(), x.to(dev)), ref104.eval()(x), "h104 eval", rtol=2e-4, atol=2e-5)
+
+
+def test_stat_slots_survive_arena_wraparound_and_capture():
+    """The slot arena is re-zeroed when it wraps (eager) and a captured graph zeroes its own arena at every replay:
+    many BatchNorms in a row and a replayed graph give the same result as the first call."""
+    from kp_gnn_amd import ops_dense
+    dev = _dev()
+    torch.manual_seed(1)
+    bn = torch.nn.BatchNorm1d(256).to(dev).train()
+    x = torch.randn(3000, 256, device=dev) + 2.0
+    first = ops_dense.batch_norm_act(x, bn).clone()
+    for _ in range(2 * (ops_dense._EAGER_DOUBLES // (8 * 2 * 256)) + 3):     # wraps the eager arena twice
+        last = ops_dense.batch_norm_act(x, bn)
+    assert torch.equal(first, last)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops_dense.batch_norm_act(x, bn)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = [ops_dense.batch_norm_act(x, bn) for _ in range(3)]
+    for _ in range(3):
+        graph.replay()
+        ops_dense.batch_norm_act(x, bn)            # eager work between replays uses the other arena
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(first, o)
