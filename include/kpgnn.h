@@ -258,11 +258,13 @@ typedef struct kpgnn_tgs_desc {
     int64_t out_stride;
     const float* gout;          /* device [M, D], row stride gout_stride (backward) */
     int64_t gout_stride;
-    float* gtable;              /* device [R, D] contiguous, accumulated into with fp32 atomics (backward) */
+    float* gtable;              /* device [R, D] contiguous, OVERWRITTEN (backward; no atomics: bitwise reproducible) */
+    void* workspace; size_t workspace_bytes;   /* backward: >= kpgnn_table_gather_sum_bwd_workspace_bytes(M, D, R) */
 } kpgnn_tgs_desc;
 
 int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
 int kpgnn_table_gather_sum_bwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
+size_t kpgnn_table_gather_sum_bwd_workspace_bytes(int64_t M, int32_t D, int32_t R);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-mode BatchNorm1d (+ optional ReLU, + optional residual) over [N, C] rows, forward and backward.  These
@@ -402,6 +404,26 @@ typedef struct kpgnn_linear_bn_desc {
 } kpgnn_linear_bn_desc;
 
 int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph readout over a collated batch (models/GraphRegression.py:46-51: PyG global_add_pool / global_mean_pool):
+ *   out[g,:] = sum (mode 0) or mean (mode 1) of x[n,:] over the nodes n of graph g;  gx[n,:] = gout[batch[n],:] (/ count)
+ * The nodes of a graph are contiguous (graph_ptr[g] .. graph_ptr[g+1]), rows are added in node order: bitwise
+ * reproducible, unlike a scatter with fp32 atomics.  One launch per direction.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_pool_desc {
+    int64_t N;                  /* nodes */
+    int32_t G, D, mode;         /* graphs, feature width, 0 = sum / 1 = mean */
+    const int32_t* graph_ptr;   /* device [G+1], non-decreasing, graph_ptr[G] == N */
+    const int64_t* batch;       /* device [N]: graph of node n (backward only) */
+    const float* x; int64_t x_stride;      /* device [N,D] (forward) */
+    float* out;                 /* device [G,D] contiguous (forward) */
+    const float* gout;          /* device [G,D] contiguous (backward) */
+    float* gx; int64_t gx_stride;          /* device [N,D] (backward, overwritten) */
+} kpgnn_pool_desc;
+
+int kpgnn_segment_pool_fwd(const kpgnn_pool_desc* d, kpgnn_stream_t stream);
+int kpgnn_segment_pool_bwd(const kpgnn_pool_desc* d, kpgnn_stream_t stream);
 
 /* Identifier of the capture the stream is part of (hipStreamGetCaptureInfo), 0 when it is not capturing: lets a
  * caller that zeroes its statistics slots once per step put that memset into every graph it captures. */

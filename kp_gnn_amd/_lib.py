@@ -144,6 +144,15 @@ class TgsDesc(ctypes.Structure):
         ("M", c_i64), ("C", c_i32), ("D", c_i32), ("R", c_i32),
         ("idx", c_vp), ("col_offset", c_vp), ("table", c_vp), ("bias", c_vp),
         ("out", c_vp), ("out_stride", c_i64), ("gout", c_vp), ("gout_stride", c_i64), ("gtable", c_vp),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class PoolDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("G", c_i32), ("D", c_i32), ("mode", c_i32),
+        ("graph_ptr", c_vp), ("batch", c_vp), ("x", c_vp), ("x_stride", c_i64), ("out", c_vp),
+        ("gout", c_vp), ("gx", c_vp), ("gx_stride", c_i64),
     ]
 
 
@@ -169,6 +178,8 @@ SIGNATURES = {
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
+    "kpgnn_segment_pool_fwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
+    "kpgnn_segment_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
     "kpgnn_stat_slot_bytes": (ctypes.c_size_t, [c_i32]),
     "kpgnn_stream_capture_id": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
@@ -181,6 +192,7 @@ SIGNATURES = {
     "kpgnn_hop_mlp_bwd": (ctypes.c_int, [ctypes.POINTER(HopMlpDesc), c_vp]),
     "kpgnn_table_gather_sum_fwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
     "kpgnn_table_gather_sum_bwd": (ctypes.c_int, [ctypes.POINTER(TgsDesc), c_vp]),
+    "kpgnn_table_gather_sum_bwd_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i32]),
 }
 
 _lib = None

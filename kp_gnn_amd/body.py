@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
-from .ops import DictPeripheral, embedding_rows, table_gather_sum
+from .ops import DictPeripheral, embedding_rows, segment_pool, table_gather_sum
 from .ops_dense import batch_norm_act
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
@@ -82,6 +82,8 @@ def _get(data, name):
 
 def global_add_pool(x, batch, size=None):
     size = int(batch[-1].item()) + 1 if size is None else size
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+        return segment_pool(x, batch, size)          # segmented sum in node order: one launch, bitwise reproducible
     return x.new_zeros((size,) + tuple(x.shape[1:])).index_add_(0, batch, x)
 
 
@@ -491,6 +493,8 @@ class GraphRegression(nn.Module):
         if self.pooling_method == "sum":
             return global_add_pool(x, batch, size)
         if self.pooling_method == "mean":
+            if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+                return segment_pool(x, batch, size, mean=True)
             cnt = x.new_zeros(size).index_add_(0, batch, x.new_ones(batch.numel()))
             return global_add_pool(x, batch, size) / cnt.clamp(min=1).unsqueeze(-1)
         idx = batch.view(-1, 1).expand_as(x)

@@ -4,8 +4,11 @@
 // concat -> Linear (layers/feature_encoder.py:62-67, called from models/GNNs.py:172-179/:393-400/:637-644)
 // and, in backward, 9 sort-based embedding_dense_backward calls over ~N*K*T indices that hit a handful of
 // distinct rows.  Here the (tiny) projected tables sit in LDS; a sub-group of G lanes owns one row m, reads
-// its C uint16 indices with one coalesced load and sums C LDS rows; backward accumulates gout rows into an
-// LDS copy of the table grads with ds_add_f32 and flushes once per block with global fp32 atomics.
+// its C uint16 indices with one coalesced load and sums C LDS rows.  Backward (tgs_bwd_kernel) is a histogram without
+// atomics: thread = feature column, a group of threads walks ITS contiguous run of rows in order and adds into a
+// group-private LDS copy of the table grads (column-private: no races, fixed order), the groups of a block are added in
+// order into a per-block slab row and the slab is reduced in block order: bitwise reproducible (round 1 used ds_add_f32
+// + global fp32 atomics, whose order varies between runs).
 // Wide tables are split by feature columns across blockIdx.y so that each block's slice fits LDS.
 #include "kpgnn_common.h"
 
@@ -32,7 +35,7 @@ struct TgsParams {
     float* gtable;
 };
 
-template <int VEC, int G, bool BWD>
+template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock)
 tgs_kernel(const TgsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [R, Ds]
@@ -40,7 +43,7 @@ tgs_kernel(const TgsParams p) {
     const int col_base = blockIdx.y * Ds;
     for (int t = threadIdx.x; t < R * Ds; t += kBlock) {
         const int r = t / Ds, c = t - r * Ds;
-        lds[t] = BWD ? 0.f : p.table[(int64_t)r * p.D + col_base + c];
+        lds[t] = p.table[(int64_t)r * p.D + col_base + c];
     }
     __syncthreads();
     constexpr int ROWS = kBlock / G;
@@ -55,17 +58,10 @@ tgs_kernel(const TgsParams p) {
         const int64_t m = tile * ROWS + sg;
         if (m >= p.M) continue;
         float acc[VEC];
-        if (BWD) {
-            if (col_ok) {
-                T g = *reinterpret_cast<const T*>(p.gout + m * p.gout_stride + col_base + c0);
-                for (int q = 0; q < VEC; ++q) acc[q] = reinterpret_cast<const float*>(&g)[q];
-            }
-        } else {
-            for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-            if (col_ok && p.bias) {
-                T b = *reinterpret_cast<const T*>(p.bias + col_base + c0);
-                for (int q = 0; q < VEC; ++q) acc[q] = reinterpret_cast<const float*>(&b)[q];
-            }
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        if (col_ok && p.bias) {
+            T b = *reinterpret_cast<const T*>(p.bias + col_base + c0);
+            for (int q = 0; q < VEC; ++q) acc[q] = reinterpret_cast<const float*>(&b)[q];
         }
         for (int cb = 0; cb < p.C; cb += G) {
             int myrow = 0;
@@ -74,54 +70,131 @@ tgs_kernel(const TgsParams p) {
             for (int t = 0; t < cnt; ++t) {
                 const int row = __shfl(myrow, sg_lane0 + t);
                 if (!col_ok) continue;
-                float* lrow = lds + row * Ds + c0;
-                if (BWD) {
-                    for (int q = 0; q < VEC; ++q) atomicAdd(lrow + q, acc[q]);
-                } else {
-                    T v = *reinterpret_cast<const T*>(lrow);
-                    for (int q = 0; q < VEC; ++q) acc[q] += reinterpret_cast<const float*>(&v)[q];
-                }
+                T v = *reinterpret_cast<const T*>(lds + row * Ds + c0);
+                for (int q = 0; q < VEC; ++q) acc[q] += reinterpret_cast<const float*>(&v)[q];
             }
         }
-        if (!BWD && col_ok) {
+        if (col_ok) {
             T o;
             for (int q = 0; q < VEC; ++q) reinterpret_cast<float*>(&o)[q] = acc[q];
             *reinterpret_cast<T*>(p.out + m * p.out_stride + col_base + c0) = o;
         }
     }
-    if (BWD) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < R * Ds; t += kBlock) {
-            const float v = lds[t];
-            if (v != 0.f) {
-                const int r = t / Ds, c = t - r * Ds;
-                atomicAdd(p.gtable + (int64_t)r * p.D + col_base + c, v);
+}
+
+// Backward: gtable[col_offset[c] + idx[m,c], :] += gout[m, :].  Block = NG groups of CW threads (CW = pow2 >= Ds); the
+// block's contiguous run of rows is cut into NG contiguous sub-runs, group g adds ITS rows in order into its private
+// accumulator table [R][CW] in LDS (thread = column: plain read-modify-write, no races); then the groups are added in
+// order and leave as slab row blockIdx.x.  slab: [gridDim.x][R][D].
+__global__ void __launch_bounds__(kBlock)
+tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [NG][R][CW]
+    const int Ds = p.Ds, R = p.R;
+    const int col_base = blockIdx.y * Ds;
+    for (int t = threadIdx.x; t < NG * R * CW; t += kBlock) lds[t] = 0.f;
+    __syncthreads();
+    const int grp = threadIdx.x / CW, col = threadIdx.x % CW;
+    const int64_t per_block = (p.M + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per_block;
+    const int64_t b1 = b0 + per_block < p.M ? b0 + per_block : p.M;
+    if (grp < NG && col < Ds && b0 < b1) {
+        const int64_t per_grp = (b1 - b0 + NG - 1) / NG;
+        const int64_t m0 = b0 + grp * per_grp;
+        const int64_t m1 = m0 + per_grp < b1 ? m0 + per_grp : b1;
+        float* acc = lds + (int64_t)grp * R * CW + col;
+        // four rows per trip: their loads are independent of the LDS read-modify-writes of the previous rows
+        for (int64_t m = m0; m < m1; m += 4) {
+            float g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = m + u < m1 ? p.gout[(m + u) * p.gout_stride + col_base + col] : 0.f;
+            for (int c = 0; c < p.C; ++c) {
+                const int off = p.col_offset[c];
+                int row[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) row[u] = m + u < m1 ? off + (int)p.idx[(m + u) * p.C + c] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (row[u] >= 0) acc[row[u] * CW] += g[u];
             }
         }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * Ds; t += kBlock) {
+        const int r = t / Ds, c = t - r * Ds;
+        float v = 0.f;
+        for (int g = 0; g < NG; ++g) v += lds[((int64_t)g * R + r) * CW + c];
+        slab[((int64_t)blockIdx.x * R + r) * p.D + col_base + c] = v;
     }
 }
 
 template <int VEC, int G>
-int launch(const TgsParams& p, bool bwd, int splits, size_t lds, hipStream_t s) {
+int launch(const TgsParams& p, int splits, size_t lds, hipStream_t s) {
     const int64_t tiles = (p.M + (kBlock / G) - 1) / (kBlock / G);
     int64_t gx = (int64_t)device_facts().cu_count * (lds > 40 * 1024 ? 1 : 3);
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)splits);
-    if (bwd) {
-        if (lds > 64 * 1024)
-            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_kernel<VEC, G, true>, lds));
-        hipLaunchKernelGGL((tgs_kernel<VEC, G, true>), grid, dim3(kBlock), lds, s, p);
-    } else {
-        if (lds > 64 * 1024)
-            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_kernel<VEC, G, false>, lds));
-        hipLaunchKernelGGL((tgs_kernel<VEC, G, false>), grid, dim3(kBlock), lds, s, p);
-    }
+    if (lds > 64 * 1024)
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_kernel<VEC, G>, lds));
+    hipLaunchKernelGGL((tgs_kernel<VEC, G>), grid, dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("tgs_kernel");
     return KPGNN_OK;
 }
 
-int run(const kpgnn_tgs_desc* d, bool bwd, hipStream_t s) {
+// Backward plan: column splits so that at least one [R][CW] accumulator table fits LDS, groups per block, grid.
+struct BwdPlan { int splits, Ds, CW, NG, gx; size_t lds, ws_bytes; };
+constexpr size_t kMaxLdsBwd = 144 * 1024;
+
+bool bwd_plan(int64_t M, int D, int R, BwdPlan* pl) {
+    for (int sct = 1; sct <= D; ++sct) {
+        if (D % sct) continue;
+        const int w = D / sct;
+        if (w > kBlock) continue;
+        int cw = 1;
+        while (cw < w) cw <<= 1;
+        const size_t one = sizeof(float) * (size_t)R * cw;
+        if (one > kMaxLdsBwd) continue;
+        int ng = kBlock / cw;
+        while (ng > 1 && one * ng > kMaxLdsBwd) ng >>= 1;
+        pl->splits = sct; pl->Ds = w; pl->CW = cw; pl->NG = ng; pl->lds = one * ng;
+        // rows per group >= 16 where possible; at most one block per CU and a slab of <= 32 MB
+        int64_t gx = (M + 16 * ng - 1) / (16 * ng);
+        const int64_t cap_cu = device_facts().cu_count;
+        const int64_t cap_ws = (int64_t)(32u << 20) / ((int64_t)sizeof(float) * R * D);
+        if (gx > cap_cu) gx = cap_cu;
+        if (gx > cap_ws) gx = cap_ws;
+        if (gx < 1) gx = 1;
+        pl->gx = (int)gx;
+        pl->ws_bytes = sizeof(float) * (size_t)gx * R * D;
+        return true;
+    }
+    return false;
+}
+
+int run_bwd(const kpgnn_tgs_desc* d, hipStream_t s) {
+    KPGNN_REQUIRE(d != nullptr, "table_gather_sum_bwd: NULL descriptor");
+    KPGNN_REQUIRE(d->M >= 0 && d->C >= 1 && d->D >= 1 && d->R >= 1, "table_gather_sum_bwd: bad M=%lld C=%d D=%d R=%d",
+                  (long long)d->M, d->C, d->D, d->R);
+    KPGNN_REQUIRE(d->gtable != nullptr, "table_gather_sum_bwd: NULL gtable");
+    if (d->M == 0) { KPGNN_HIP_TRY(hipMemsetAsync(d->gtable, 0, sizeof(float) * (size_t)d->R * d->D, s)); return KPGNN_OK; }
+    KPGNN_REQUIRE(d->idx && d->col_offset && d->gout && d->gout_stride >= d->D, "table_gather_sum_bwd: NULL idx/col_offset/gout");
+    BwdPlan pl;
+    if (!bwd_plan(d->M, d->D, d->R, &pl))
+        return fail(KPGNN_ELIMIT, "table_gather_sum_bwd: R=%d rows do not fit LDS at any column split of D=%d", d->R, d->D);
+    KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_gather_sum_bwd: workspace too small (%zu < %zu)",
+                  (size_t)d->workspace_bytes, pl.ws_bytes);
+    TgsParams p;
+    p.M = d->M; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = pl.Ds; p.idx = d->idx; p.col_offset = d->col_offset;
+    p.table = nullptr; p.bias = nullptr; p.out = nullptr; p.out_stride = 0;
+    p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
+    KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_bwd_kernel, pl.lds));
+    hipLaunchKernelGGL(tgs_bwd_kernel, dim3(pl.gx, pl.splits), dim3(kBlock), pl.lds, s, p, pl.CW, pl.NG, (float*)d->workspace);
+    KPGNN_LAUNCH_CHECK("tgs_bwd_kernel");
+    return slab_reduce((const float*)d->workspace, pl.gx, (int64_t)d->R * d->D, d->gtable, (int64_t)d->R * d->D, nullptr, 0, nullptr, s);
+}
+
+int run(const kpgnn_tgs_desc* d, hipStream_t s) {
+    const bool bwd = false;
     KPGNN_REQUIRE(d != nullptr, "table_gather_sum: NULL descriptor");
     KPGNN_REQUIRE(d->M >= 0 && d->C >= 1 && d->D >= 1 && d->R >= 1, "table_gather_sum: bad M=%lld C=%d D=%d R=%d",
                   (long long)d->M, d->C, d->D, d->R);
@@ -153,7 +226,7 @@ int run(const kpgnn_tgs_desc* d, bool bwd, hipStream_t s) {
     const size_t lds = (size_t)d->R * Ds * sizeof(float);
     int g = 4;
     while (g * vec < Ds) g <<= 1;
-#define KP_TGS(V, GG) launch<V, GG>(p, bwd, splits, lds, s)
+#define KP_TGS(V, GG) launch<V, GG>(p, splits, lds, s)
     switch (vec * 100 + g) {
         case 404: return KP_TGS(4, 4); case 408: return KP_TGS(4, 8); case 416: return KP_TGS(4, 16);
         case 432: return KP_TGS(4, 32); case 464: return KP_TGS(4, 64);
@@ -170,9 +243,15 @@ int run(const kpgnn_tgs_desc* d, bool bwd, hipStream_t s) {
 }  // namespace kpgnn
 
 extern "C" int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream) {
-    return kpgnn::run(d, false, (hipStream_t)stream);
+    return kpgnn::run(d, (hipStream_t)stream);
 }
 
 extern "C" int kpgnn_table_gather_sum_bwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream) {
-    return kpgnn::run(d, true, (hipStream_t)stream);
+    return kpgnn::run_bwd(d, (hipStream_t)stream);
+}
+
+extern "C" size_t kpgnn_table_gather_sum_bwd_workspace_bytes(int64_t M, int32_t D, int32_t R) {
+    kpgnn::BwdPlan pl;
+    if (M < 1 || D < 1 || R < 1 || !kpgnn::bwd_plan(M, D, R, &pl)) return 0;
+    return pl.ws_bytes;
 }

@@ -508,11 +508,14 @@ class TableGatherSum(torch.autograd.Function):
         gout = _last_contig(gout)
         R, D = ctx.shape
         M, C = idx.shape
-        gtable = torch.zeros((R, D), dtype=torch.float32, device=gout.device)
+        gtable = torch.empty((R, D), dtype=torch.float32, device=gout.device)
+        nb = int(lib.kpgnn_table_gather_sum_bwd_workspace_bytes(M, D, R))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=gout.device)
         d = _lib.TgsDesc()
         d.M, d.C, d.D, d.R = M, C, D, R
         d.idx, d.col_offset = idx.data_ptr(), col_offset.data_ptr()
         d.gout, d.gout_stride, d.gtable = gout.data_ptr(), gout.stride(0), gtable.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(gout.device):
             _lib.check(lib.kpgnn_table_gather_sum_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_table_gather_sum_bwd")
         gbias = gout.sum(0) if ctx.has_bias else None
@@ -577,3 +580,65 @@ def embedding_rows(weight, idx, padding_idx=None):
         weight = _ZeroRowGrad.apply(weight, int(padding_idx))
     out = TableGatherSum.apply(weight, None, rec[1], rec[2])
     return out.view(*idx.shape, weight.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------ graph readout
+_GPTR = "_kpgnn_graph_ptr"
+
+
+def graph_ptr_of(batch, num_graphs):
+    """int32 [G+1] node offsets of the graphs of a collated batch (nodes of a graph are contiguous, as PyG's collate
+    lays them out), cached on the `batch` tensor; checks once that `batch` is sorted (one sync per batch object)."""
+    rec = getattr(batch, _GPTR, None)
+    if rec is not None and rec[0] == (batch._version, num_graphs):
+        return rec[1]
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.KpgnnError("graph readout: first use of a batch vector inside a hipGraph capture (its order check needs a "
+                              "host sync); run one eager step on the batch before capturing")
+    if batch.numel() > 1 and bool((batch[1:] < batch[:-1]).any().item()):
+        raise ValueError("graph readout needs the nodes of every graph to be contiguous (sorted `batch`)")
+    ptr = torch.searchsorted(batch, torch.arange(num_graphs + 1, device=batch.device, dtype=batch.dtype)).to(torch.int32)
+    try:
+        setattr(batch, _GPTR, ((batch._version, num_graphs), ptr))
+    except Exception:  # pragma: no cover
+        pass
+    return ptr
+
+
+class SegmentPool(torch.autograd.Function):
+    """out[g] = sum / mean of the rows of graph g (kpgnn_segment_pool_*): one launch per direction, no atomics."""
+
+    @staticmethod
+    def forward(ctx, x, batch, ptr, num_graphs, mean):
+        lib = _lib.load()
+        x = _last_contig(x)
+        N, D = x.shape
+        out = torch.empty((num_graphs, D), dtype=torch.float32, device=x.device)
+        d = _lib.PoolDesc()
+        d.N, d.G, d.D, d.mode = N, num_graphs, D, 1 if mean else 0
+        d.graph_ptr, d.x, d.x_stride, d.out = ptr.data_ptr(), x.data_ptr(), x.stride(0), out.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.kpgnn_segment_pool_fwd(ctypes.byref(d), _stream(x)), "kpgnn_segment_pool_fwd")
+        ctx.save_for_backward(batch, ptr)
+        ctx.dims = (N, D, num_graphs, mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        batch, ptr = ctx.saved_tensors
+        N, D, G, mean = ctx.dims
+        lib = _lib.load()
+        gout = gout.contiguous()
+        gx = torch.empty((N, D), dtype=torch.float32, device=gout.device)
+        d = _lib.PoolDesc()
+        d.N, d.G, d.D, d.mode = N, G, D, 1 if mean else 0
+        d.graph_ptr, d.batch, d.gout, d.gx, d.gx_stride = ptr.data_ptr(), batch.data_ptr(), gout.data_ptr(), gx.data_ptr(), D
+        with torch.cuda.device(gout.device):
+            _lib.check(lib.kpgnn_segment_pool_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_segment_pool_bwd")
+        return gx, None, None, None, None
+
+
+def segment_pool(x, batch, num_graphs, mean=False):
+    """Sum / mean readout of [N,D] node rows per graph on the HIP kernels (fp32 device tensors, int64 sorted batch)."""
+    _require_cuda(x, batch)
+    return SegmentPool.apply(x, batch.long() if batch.dtype != torch.int64 else batch, graph_ptr_of(batch, num_graphs), num_graphs, mean)

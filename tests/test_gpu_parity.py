@@ -944,3 +944,34 @@ def test_stat_slots_survive_arena_wraparound_and_capture():
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(first, o)
+
+
+@pytest.mark.parametrize("D", [104, 13, 1, 96, 250])
+@pytest.mark.parametrize("mean", [False, True])
+def test_segment_pool_vs_index_add(D, mean):
+    """Graph readout (kpgnn_segment_pool_*) vs the framework's zero-fill + index_add_ formulation, incl. empty graphs
+    and the backward; two runs give identical bits."""
+    from kp_gnn_amd.ops import segment_pool
+    dev = _dev()
+    g = torch.Generator().manual_seed(D)
+    sizes = torch.randint(0, 40, (300,), generator=g)
+    sizes[7] = 0
+    sizes[299] = 0
+    batch = torch.repeat_interleave(torch.arange(300), sizes)
+    N = int(sizes.sum())
+    x = torch.randn(N, D, generator=g)
+    w = torch.randn(300, D, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.zeros(300, D).index_add_(0, batch, xr)
+    if mean:
+        ref = ref / sizes.clamp(min=1).unsqueeze(-1)
+    (ref * w).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    bd = batch.to(dev)
+    out = segment_pool(xd, bd, 300, mean=mean)
+    (out * w.to(dev)).sum().backward()
+    _close(out, ref, "pool")
+    _close(xd.grad, xr.grad, "pool grad")
+    assert torch.equal(out, segment_pool(xd, bd, 300, mean=mean))
+    with pytest.raises(ValueError):
+        segment_pool(xd, torch.flip(bd, [0]).contiguous(), 300)
