@@ -139,6 +139,9 @@ typedef struct kpgnn_agg_fwd_desc {
     /* Rows of ptab (0 = unknown).  When given and small, the dictionary and theta are staged in LDS next to the
      * code tables, so the per-hop epilogue has no dependent global loads left. */
     int32_t n_dict;
+    /* Geometric combine computed by the launch itself: alphas [D] (device) - theta[k,d] = softmax_k(a (1-a)^k) with
+     * a = sigmoid(alphas[d]) (combine.py:43-50) is then an OUTPUT, written to `theta` ([K,D]) for the backward. */
+    const float* alphas;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

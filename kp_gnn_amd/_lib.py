@@ -27,7 +27,7 @@ class AggFwdDesc(ctypes.Structure):
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
-        ("x_slot", c_vp * 16), ("n_dict", c_i32),
+        ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp),
     ]
 
 

@@ -73,6 +73,8 @@ struct FwdParams {
     float* out; int64_t o_sn, o_sk;
     float* pre;
     const float* theta;
+    const float* alphas;        // geometric combine computed in-kernel (theta is then this launch's OUTPUT via theta_out)
+    float* theta_out;
     float* hout;
     const float* xbias;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
@@ -100,6 +102,27 @@ agg_fwd_kernel(const FwdParams p) {
         // theta and the peripheral dictionary ride along: the per-hop epilogue then has no dependent global load
         float* th_l = lds_tab + ((n0 + nk + 3) & ~3);
         float* pt_l = th_l + ((p.lds_theta + 3) & ~3);
+        if (p.alphas) {
+            // theta[k,d] = softmax_k(a (1-a)^k), a = sigmoid(alphas[d]) (combine.py:43-50): K*D values, rebuilt by every
+            // block instead of a launch of their own; block 0 publishes them for the backward
+            for (int d = threadIdx.x; d < D; d += kBlock) {
+                const float a = 1.0f / (1.0f + __expf(-p.alphas[d]));
+                const float q = 1.0f - a;
+                float pw = 1.0f, mx = -INFINITY;
+                for (int k = 0; k < p.K; ++k) { mx = fmaxf(mx, a * pw); pw *= q; }
+                float sum = 0.f;
+                pw = 1.0f;
+                for (int k = 0; k < p.K; ++k) { sum += __expf(a * pw - mx); pw *= q; }
+                const float inv = 1.0f / sum;
+                pw = 1.0f;
+                for (int k = 0; k < p.K; ++k) {
+                    const float th = __expf(a * pw - mx) * inv;
+                    th_l[k * D + d] = th;
+                    if (blockIdx.x == 0) p.theta_out[(int64_t)k * D + d] = th;
+                    pw *= q;
+                }
+            }
+        } else
         for (int t = threadIdx.x; t < p.lds_theta; t += kBlock) th_l[t] = p.theta[t];
         for (int t = threadIdx.x; t < p.lds_ptab; t += kBlock) pt_l[t] = p.ptab[t];
         if (p.lds_theta) thp = th_l;
@@ -649,6 +672,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->mode != KPGNN_MODE_GCN || d->dis, "aggregate_fwd: GCN mode needs dis");
     const bool combine = d->theta != nullptr;
     KPGNN_REQUIRE(combine ? d->hout != nullptr : d->out != nullptr, "aggregate_fwd: NULL output");
+    KPGNN_REQUIRE(!d->alphas || combine, "aggregate_fwd: alphas needs the theta buffer it fills");
     int tab = 0;
     size_t lds = 0;
     if (d->use_tables)
@@ -678,6 +702,14 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.table0 = d->table0; p.tablek = d->tablek;
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
+    p.alphas = nullptr; p.theta_out = nullptr;
+    if (d->alphas) {
+        if (p.lds_theta) { p.alphas = d->alphas; p.theta_out = const_cast<float*>(d->theta); }   // theta staged in LDS: computed there
+        else {                                                                                    // otherwise by a launch of its own
+            const int rc = geo_theta_fwd_launch(d->alphas, d->K, d->D, const_cast<float*>(d->theta), (hipStream_t)stream);
+            if (rc != KPGNN_OK) return rc;
+        }
+    }
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     KPGNN_REQUIRE(p.uid == nullptr || (p.ptab != nullptr && p.uid_stride >= d->K), "aggregate_fwd: dictionary P needs ptab and uid_stride >= K");
     uintptr_t slot_bits = 0;            // low address bits of ALL per-hop inputs OR-ed: the least aligned one decides the vector width

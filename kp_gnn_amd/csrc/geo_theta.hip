@@ -47,13 +47,19 @@ __global__ void geo_theta_bwd_kernel(const float* __restrict__ alpha, const floa
 }  // namespace
 }  // namespace kpgnn
 
+namespace kpgnn {
+int geo_theta_fwd_launch(const float* alpha, int K, int D, float* theta, hipStream_t s) {
+    hipLaunchKernelGGL(geo_theta_fwd_kernel, dim3((D + 63) / 64), dim3(64), 0, s, alpha, K, D, theta);
+    KPGNN_LAUNCH_CHECK("geo_theta_fwd_kernel");
+    return KPGNN_OK;
+}
+}  // namespace kpgnn
+
 using namespace kpgnn;
 
 extern "C" int kpgnn_geo_theta_fwd(const float* alpha, int32_t K, int32_t D, float* theta, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(alpha && theta && K >= 1 && D >= 1, "geo_theta_fwd: bad arguments K=%d D=%d", K, D);
-    hipLaunchKernelGGL(geo_theta_fwd_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha, K, D, theta);
-    KPGNN_LAUNCH_CHECK("geo_theta_fwd_kernel");
-    return KPGNN_OK;
+    return geo_theta_fwd_launch(alpha, K, D, theta, (hipStream_t)stream);
 }
 
 extern "C" int kpgnn_geo_theta_bwd(const float* alpha, const float* theta, const float* gtheta, int32_t K, int32_t D,

@@ -58,6 +58,9 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr);
 
+// theta[k,d] = softmax_k(a (1-a)^k), a = sigmoid(alpha[d])  (geo_theta.hip)
+int geo_theta_fwd_launch(const float* alpha, int K, int D, float* theta, hipStream_t s);
+
 // Count-matrix x g-tile table gradients on the matrix cores (table_grad_mfma.hip): *handled tells whether the launch
 // was done; otherwise kpgnn_table_grad falls back to its register-walk kernel.
 int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled);

@@ -45,7 +45,7 @@ class KPGCNConv(KHopMessagePassing, EdgeCodeTables):
         t0, tk = self._tables()
         if isinstance(self.combine, GeometricCombine):
             h = khop_aggregate(x, csr, k_act, MODE_GCN, table0=t0, tablek=tk, periph=peripheral_attr,
-                               theta=self.combine.theta(), xbias=xbias)
+                               theta=self.combine.alphas, xbias=xbias)
         else:
             h = self.combine(khop_aggregate(x, csr, k_act, MODE_GCN, table0=t0, tablek=tk, periph=peripheral_attr,
                                             xbias=xbias))

@@ -52,7 +52,7 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
         t0, tk = self._tables()
         if isinstance(self.combine, GeometricCombine):
             h = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
-                               theta=self.combine.theta(), xbias=xbias, share_slot_grads=_history)   # N,H
+                               theta=self.combine.alphas, xbias=xbias, share_slot_grads=_history)   # N,H
         else:
             xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
                                 xbias=xbias, share_slot_grads=_history)                       # N,k,H

@@ -104,7 +104,7 @@ class DictPeripheral:
 
 
 def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None,
-                      xs=None):
+                      xs=None, alphas=None):
     """Launch kpgnn_aggregate_fwd.  x is [N,k,D], or None with xs = k per-hop [N,D] tensors (row stride shared).
     Returns (out or hout, pre or None)."""
     lib = _lib.load()
@@ -143,6 +143,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     if theta is not None:
         out = torch.empty((N, D), dtype=torch.float32, device=dev)
         d.theta, d.hout = theta.data_ptr(), out.data_ptr()
+        d.alphas = _ptr(alphas)     # geometric combine: the launch fills `theta` itself
     else:
         out = torch.empty((N, K, D), dtype=torch.float32, device=dev)
         d.out, d.o_sn, d.o_sk = out.data_ptr(), out.stride(0), out.stride(1)
@@ -320,13 +321,19 @@ class KHopAggregate(torch.autograd.Function):
             table0 = table0.contiguous()
             tablek = tablek.contiguous() if tablek is not None else None
             _check_codes(csr, k_act, table0, tablek)
-        if theta is not None:
+        alphas = None
+        if theta is not None and theta.dim() == 1:
+            # GeometricCombine.alphas [D]: theta = softmax_k(a (1-a)^k) is computed by the aggregation launch itself
+            alphas = theta.contiguous()
+            theta = torch.empty((k_act, alphas.numel()), dtype=torch.float32, device=alphas.device)
+        elif theta is not None:
             theta = theta.contiguous()
         if ptab is not None:
             ptab = ptab.contiguous()
         need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
         out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre,
-                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None)
+                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None, alphas=alphas)
+        ctx.alphas = alphas
         ctx.csr, ctx.k_act, ctx.mode, ctx.uid = csr, k_act, mode, uid
         ctx.has_tables = table0 is not None
         ctx.n_code0 = table0.shape[0] if table0 is not None else 0
@@ -386,6 +393,13 @@ class KHopAggregate(torch.autograd.Function):
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
         if tables_in_gather:
             gt0, gtk = a0, ak
+        if gtheta is not None and ctx.alphas is not None:   # d/dalphas through theta (geo_theta.hip), one tiny launch
+            galpha = torch.empty_like(ctx.alphas)
+            lib = _lib.load()
+            with torch.cuda.device(galpha.device):
+                _lib.check(lib.kpgnn_geo_theta_bwd(ctx.alphas.data_ptr(), theta.data_ptr(), gtheta.data_ptr(), k_act,
+                                                   ctx.alphas.numel(), galpha.data_ptr(), _stream(galpha)), "kpgnn_geo_theta_bwd")
+            gtheta = galpha
         geps = None
         if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
             xe = x_saved
@@ -433,6 +447,8 @@ def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, e
                    share_slot_grads=False):
     """x: [N,k,D] tensor, or a list/tuple of k per-hop [N,D] tensors (no stacking copy).
     periph: dense [N,k,D] tensor, a DictPeripheral, or None.
+    theta: [k,D] hop weights of a fused combine, or the [D] `alphas` of a GeometricCombine (theta is then computed by the
+    aggregation launch itself and differentiated back to alphas).
     share_slot_grads (per-hop list only): the caller guarantees the GNNPlus history pattern - slot k of layer m is the
     output of layer m-1-k, so every state is read as slot 0 by the layer right after it and as slots >= 1 only by LATER
     layers, whose backward autograd runs first.  The backward then accumulates a state's slot gradients in ONE buffer
