@@ -309,6 +309,9 @@ typedef struct kpgnn_bn_bwd_desc {
     float* dgamma; float* dbeta;            /* device [C] (overwritten); NULL with reduce_only */
     double* stat_slot;                      /* device, kpgnn_stat_slot_bytes(C), zero on entry */
     int32_t reduce_only;
+    /* Optional, for z = bn(x) + residual: the residual branch's gradient (= dz) is ADDED in place to this [N,C]
+     * buffer by the apply pass (a state read by several layers collects its gradient in one buffer). */
+    float* residual_grad; int64_t rg_stride;
 } kpgnn_bn_bwd_desc;
 
 int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);

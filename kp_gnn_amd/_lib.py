@@ -85,7 +85,7 @@ class BnBwdDesc(ctypes.Structure):
         ("x", c_vp), ("x_stride", c_i64), ("dz", c_vp), ("dz_stride", c_i64),
         ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("dx", c_vp), ("dx_stride", c_i64), ("dgamma", c_vp), ("dbeta", c_vp),
-        ("stat_slot", c_vp), ("reduce_only", c_i32),
+        ("stat_slot", c_vp), ("reduce_only", c_i32), ("residual_grad", c_vp), ("rg_stride", c_i64),
     ]
 
 

@@ -43,6 +43,7 @@ struct BnParams {
     const double* in_slot;             // consumer side
     double* out_slot;                  // producer side
     float* dgamma; float* dbeta;
+    float* racc; int64_t racs;         // bwd apply: racc[r,:] += dz[r,:] (the residual branch's gradient, accumulated in place)
 };
 
 __device__ __forceinline__ double slot_sum(const double* slot, int C, int which, int c) {
@@ -219,6 +220,13 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_apply_kernel(const BnParams p) 
             o[q] = g[q] * istd[q] * (dy[q] - s0[q] * inv_n - xh * s1[q] * inv_n);
         }
         stv<VEC>(p.z + r * p.zs + c0, o);
+        if (p.racc) {                       // z = bn(x) + residual: d/dresidual is the incoming gradient itself
+            float a[VEC], raw[VEC];
+            ldv<VEC>(p.racc + r * p.racs + c0, a);
+            ldv<VEC>(p.dz + r * p.dzs + c0, raw);
+            for (int q = 0; q < VEC; ++q) a[q] += raw[q];
+            stv<VEC>(p.racc + r * p.racs + c0, a);
+        }
     }
 }
 
@@ -311,14 +319,15 @@ extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d->reduce_only || (d->dx && d->dgamma && d->dbeta), "bn_bwd: NULL output");
     KPGNN_REQUIRE(d->stat_slot != nullptr, "bn_bwd: NULL stat_slot");
     int vec, g;
-    int rc = bn_shape(d->C, {d->x, d->dz, d->dx, d->gamma, d->beta, d->mean, d->invstd, d->dgamma, d->dbeta},
-                      {d->x_stride, d->dz_stride, d->dx ? d->dx_stride : 0}, &vec, &g);
+    int rc = bn_shape(d->C, {d->x, d->dz, d->dx, d->gamma, d->beta, d->mean, d->invstd, d->dgamma, d->dbeta, d->residual_grad},
+                      {d->x_stride, d->dz_stride, d->dx ? d->dx_stride : 0, d->residual_grad ? d->rg_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
     BnParams p = {};
     p.N = d->N; p.C = d->C; p.relu = d->relu;
     p.x = d->x; p.xs = d->x_stride; p.dz = d->dz; p.dzs = d->dz_stride; p.gamma = d->gamma; p.beta = d->beta;
     p.mean = const_cast<float*>(d->mean); p.invstd = const_cast<float*>(d->invstd);
     p.z = d->dx; p.zs = d->dx_stride; p.dgamma = d->dgamma; p.dbeta = d->dbeta;
+    p.racc = d->residual_grad; p.racs = d->rg_stride;
     p.out_slot = d->stat_slot;
     p.in_slot = d->stat_slot;
     hipStream_t s = (hipStream_t)stream;

@@ -26,80 +26,86 @@ struct WgParams {
 };
 struct WgPair { WgParams q[2]; };
 
+// One problem, worked through by the whole grid.  `p` is passed BY VALUE from a compile-time index of the kernel argument,
+// so its fields live in scalar registers (indexing the argument array with a runtime problem index made every use a
+// scalar load from the kernel-argument segment inside the row loop: 46 instead of 28 us per problem).
 template <int TI>
-__global__ void __launch_bounds__(512)
-wgrad_kernel(const WgPair pp, int nprob) {
+__device__ __forceinline__ void wgrad_problem(const WgParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kk = lane >> 5, c = lane & 31;
     const int o = wave * 32 + c;                 // this lane's dy column
-    // Two problems of one launch are worked through one after the other by the SAME grid: each keeps the single launch's
-    // access pattern and block count (running them side by side on half the blocks each measured 94 us against 2 x 28 us).
-#pragma unroll 1
-    for (int q = 0; q < nprob; ++q) {
-        const WgParams& p = pp.q[q];
-        const bool o_ok = o < p.O;
-        f32x16 acc[TI];
+    const bool o_ok = o < p.O;
+    f32x16 acc[TI];
 #pragma unroll
-        for (int t = 0; t < TI; ++t)
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        float bsum = 0.f;
-        float tm[TI], ts[TI], tg[TI], tb[TI];    // per-lane columns i = t*32 + c: fixed for the whole problem
-        if (p.xm) {
-#pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                const int i = t * 32 + c;
-                const bool ok = i < p.I;
-                tm[t] = ok ? p.xm[i] : 0.f; ts[t] = ok ? p.xi[i] : 0.f; tg[t] = ok ? p.xg[i] : 0.f; tb[t] = ok ? p.xb[i] : 0.f;
-            }
-        }
-        // rows of this block: pairs (r, r+1); block b takes pairs b, b+grid, ...
-        const int64_t pairs = (p.N + 1) / 2;
-        constexpr int UN = 4;
-        for (int64_t pr = blockIdx.x; pr < pairs; pr += (int64_t)gridDim.x * UN) {
-            float a[UN], b[UN][TI];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int64_t r = 2 * (pr + (int64_t)u * gridDim.x) + kk;
-                const bool r_ok = r < p.N;
-                a[u] = (r_ok && o_ok) ? p.dy[r * p.dys + o] : 0.f;
-#pragma unroll
-                for (int t = 0; t < TI; ++t) {
-                    const int i = t * 32 + c;
-                    b[u][t] = (r_ok && i < p.I) ? p.x[r * p.xs + i] : 0.f;
-                }
-            }
-            if (p.xm) {
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const bool r_ok = 2 * (pr + (int64_t)u * gridDim.x) + kk < p.N;
-#pragma unroll
-                    for (int t = 0; t < TI; ++t) {
-                        float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
-                        if (p.xrelu) v = fmaxf(v, 0.f);
-                        b[u][t] = (r_ok && t * 32 + c < p.I) ? v : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                bsum += a[u];
-#pragma unroll
-                for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
-            }
-        }
-        // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        float* out = p.slab + (int64_t)blockIdx.x * p.slab_row + p.slab_off;
+    for (int t = 0; t < TI; ++t)
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    float bsum = 0.f;
+    float tm[TI], ts[TI], tg[TI], tb[TI];        // per-lane columns i = t*32 + c: fixed for the whole problem
+    const bool tr = p.xm != nullptr;
+    if (tr) {
 #pragma unroll
         for (int t = 0; t < TI; ++t) {
             const int i = t * 32 + c;
-            for (int v = 0; v < 16; ++v) {
-                const int orow = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-                if (orow < p.O && i < p.I) out[(int64_t)orow * p.I + i] = acc[t][v];
+            const bool ok = i < p.I;
+            tm[t] = ok ? p.xm[i] : 0.f; ts[t] = ok ? p.xi[i] : 0.f; tg[t] = ok ? p.xg[i] : 0.f; tb[t] = ok ? p.xb[i] : 0.f;
+        }
+    }
+    // rows of this block: pairs (r, r+1); block b takes pairs b, b+grid, ...
+    const int64_t pairs = (p.N + 1) / 2;
+    constexpr int UN = 4;
+    for (int64_t pr = blockIdx.x; pr < pairs; pr += (int64_t)gridDim.x * UN) {
+        float a[UN], b[UN][TI];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t r = 2 * (pr + (int64_t)u * gridDim.x) + kk;
+            const bool r_ok = r < p.N;
+            a[u] = (r_ok && o_ok) ? p.dy[r * p.dys + o] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int i = t * 32 + c;
+                b[u][t] = (r_ok && i < p.I) ? p.x[r * p.xs + i] : 0.f;
             }
         }
-        bsum += __shfl_xor(bsum, 32);            // the two k halves hold different rows of the same column
-        if (kk == 0 && o_ok) out[(int64_t)p.O * p.I + o] = bsum;
+        if (tr) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const bool r_ok = 2 * (pr + (int64_t)u * gridDim.x) + kk < p.N;
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
+                    if (p.xrelu) v = fmaxf(v, 0.f);
+                    b[u][t] = (r_ok && t * 32 + c < p.I) ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            bsum += a[u];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+        }
     }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* out = p.slab + (int64_t)blockIdx.x * p.slab_row + p.slab_off;
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+        const int i = t * 32 + c;
+        for (int v = 0; v < 16; ++v) {
+            const int orow = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+            if (orow < p.O && i < p.I) out[(int64_t)orow * p.I + i] = acc[t][v];
+        }
+    }
+    bsum += __shfl_xor(bsum, 32);                // the two k halves hold different rows of the same column
+    if (kk == 0 && o_ok) out[(int64_t)p.O * p.I + o] = bsum;
+}
+
+// Two problems of one launch are worked through one after the other by the SAME grid: each keeps the single launch's
+// access pattern and block count (side by side on half the blocks each they measured 94 us against 2 x 28 us).
+template <int TI>
+__global__ void __launch_bounds__(512)
+wgrad_kernel(const WgPair pp, int nprob) {
+    wgrad_problem<TI>(pp.q[0]);
+    if (nprob > 1) wgrad_problem<TI>(pp.q[1]);
 }
 
 int wgrad_check(const kpgnn_wgrad_desc* d, const char* who) {

@@ -176,15 +176,30 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     d.dis = csr.gcn_dis().data_ptr() if mode == MODE_GCN else None
     d.g, d.g_sn, d.g_sk = g.data_ptr(), g.stride(0), g.stride(1)
     d.eps = _ptr(eps)
+    late_adds = []
     if slots:
-        gx = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(K)]
-        d.gx_sn = D
-        mask = 0
+        # The kernel writes every hop slot with ONE row stride.  Parked gradient buffers (slot_bufs) may be strided
+        # views (slices of the jumping-knowledge gradient, body.py): when all K slots are parked with the same stride
+        # the kernel accumulates into them where they are; otherwise parked buffers whose stride differs from the fresh
+        # contiguous outputs are added afterwards by the framework (rare path).
+        bufs = list(slot_bufs) if slot_bufs is not None else [None] * K
+        strides = {b.stride(0) for b in bufs if b is not None}
+        sn = D
+        if len(strides) == 1 and all(b is not None for b in bufs):
+            sn = strides.pop()
+        gx, mask = [], 0
         for k in range(K):
-            if slot_bufs is not None and slot_bufs[k] is not None:
-                gx[k] = slot_bufs[k]
+            b = bufs[k]
+            if b is not None and b.stride(0) == sn and b.stride(1) == 1:
+                gx.append(b)
                 mask |= 1 << k
+            else:
+                t = torch.empty((N, D), dtype=torch.float32, device=dev)
+                gx.append(t)
+                if b is not None:
+                    late_adds.append((k, b))
             d.gx_slot[k] = gx[k].data_ptr()
+        d.gx_sn = sn
         d.accumulate_mask = mask
     else:
         gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
@@ -205,6 +220,8 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
             e1.record()
             _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 2, (n_code0 + n_codek) if want_tables else 0),
                                    e0, e1))
+    for k, b in late_adds:
+        gx[k] = b.add_(gx[k])
     return gx, gt0, gtk
 
 
@@ -423,6 +440,15 @@ class _SlotGradCell:
         self.buf = None
 
 
+def state_cell(t):
+    """The gradient cell of a state tensor (created on first use): whoever computes part of d/dt BEFORE the state's last
+    reader runs its backward may add it to `cell.buf` instead of handing autograd a tensor to sum."""
+    c = getattr(t, "_kp_slot_cell", None)
+    if c is None:
+        c = t._kp_slot_cell = _SlotGradCell()
+    return c
+
+
 def _slot_bufs(ctx):
     return [c.buf for c in ctx.cells] if ctx.cells else None
 
@@ -498,14 +524,18 @@ class TableGatherSum(torch.autograd.Function):
     """out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :]  (kpgnn_table_gather_sum_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, table, bias, idx, col_offset):
+    def forward(ctx, table, bias, idx, col_offset, out=None):
         _require_cuda(table, bias, idx, col_offset)
         lib = _lib.load()
         table = table.contiguous()
         bias = bias.contiguous() if bias is not None else None
         M, C = idx.shape
         R, D = table.shape
-        out = torch.empty((M, D), dtype=torch.float32, device=table.device)
+        if out is None:
+            out = torch.empty((M, D), dtype=torch.float32, device=table.device)
+        else:   # OutRows: caller-provided storage for the result (rows of a wider buffer)
+            out = out.t
+            assert tuple(out.shape) == (M, D) and out.stride(1) == 1 and out.dtype == torch.float32 and out.grad_fn is None
         d = _lib.TgsDesc()
         d.M, d.C, d.D, d.R = M, C, D, R
         d.idx, d.col_offset, d.table, d.bias = idx.data_ptr(), col_offset.data_ptr(), table.data_ptr(), _ptr(bias)
@@ -535,7 +565,24 @@ class TableGatherSum(torch.autograd.Function):
         with torch.cuda.device(gout.device):
             _lib.check(lib.kpgnn_table_gather_sum_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_table_gather_sum_bwd")
         gbias = gout.sum(0) if ctx.has_bias else None
-        return gtable, gbias, None, None
+        return gtable, gbias, None, None, None
+
+
+class OutRows:
+    """Storage an operator should write its [M, D] result to instead of allocating: `rows_of(buf, col0, D)` of a wider
+    row-major buffer.  Handed to autograd Functions as a non-tensor argument: the tensor inside has no history and is no
+    registered view of the buffer (Tensor.set_), so the operator's output is an ordinary fresh tensor for autograd."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def rows_of(buf, col0, D):
+    """OutRows over columns [col0, col0 + D) of the 2-D row-major buffer `buf`."""
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    t.set_(buf.untyped_storage(), buf.storage_offset() + col0, (buf.shape[0], D), (buf.stride(0), 1))
+    return OutRows(t)
 
 
 def table_gather_sum(table, bias, idx, col_offset):
@@ -561,7 +608,7 @@ class _ZeroRowGrad(torch.autograd.Function):
         return g, None
 
 
-def embedding_rows(weight, idx, padding_idx=None):
+def embedding_rows(weight, idx, padding_idx=None, out=None):
     """weight[idx] for an integer index tensor of any shape (the bodies' input embedding, input_encoder.py:21-22; the
     layers' path encoding, KPGIN.py:92-93) through the gather-sum kernels: unlike the framework's embedding backward
     (sort + unique_by_key with a host read-back, which FAULTS when a captured hipGraph replays it) this is free of
@@ -594,8 +641,10 @@ def embedding_rows(weight, idx, padding_idx=None):
             pass
     if padding_idx is not None and weight.requires_grad:
         weight = _ZeroRowGrad.apply(weight, int(padding_idx))
-    out = TableGatherSum.apply(weight, None, rec[1], rec[2])
-    return out.view(*idx.shape, weight.shape[1])
+    if out is not None:      # [M, D] rows of a caller-provided (possibly strided) buffer
+        return TableGatherSum.apply(weight, None, rec[1], rec[2], out)
+    res = TableGatherSum.apply(weight, None, rec[1], rec[2])
+    return res.view(*idx.shape, weight.shape[1])
 
 
 # ------------------------------------------------------------------------------------------------ graph readout

@@ -81,13 +81,18 @@ def _column_stats_of(t):
 
 class BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None, ready_slot=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None, ready_slot=None,
+                out=None):
         lib = _lib.load()
         x = x if x.stride(-1) == 1 else x.contiguous()
         N, C = x.shape
         dev = x.device
         slot = ready_slot if ready_slot is not None else take_stat_slot(C, dev)
-        z = torch.empty((N, C), dtype=torch.float32, device=dev)
+        if out is None:
+            z = torch.empty((N, C), dtype=torch.float32, device=dev)
+        else:    # ops.OutRows: write the result into the caller's rows (a slice of the jumping-knowledge buffer)
+            z = out.t
+            assert tuple(z.shape) == (N, C) and z.stride(1) == 1 and z.grad_fn is None
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
@@ -106,6 +111,7 @@ class BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.relu = relu
         ctx.has_res = residual is not None
+        ctx.res_cell = getattr(residual, "_kp_slot_cell", None) if residual is not None else None
         return z
 
     @staticmethod
@@ -116,6 +122,9 @@ class BatchNormAct(torch.autograd.Function):
         N, C = x.shape
         dev = x.device
         slot = take_stat_slot(C, dev)
+        # residual branch: when the residual is a state whose gradient is being collected in a cell (ops.state_cell: a later
+        # reader already parked its share there), d/dresidual = dz is added to that buffer by the apply pass itself
+        rbuf = ctx.res_cell.buf if (ctx.res_cell is not None and ctx.needs_input_grad[3]) else None
         dx = torch.empty((N, C), dtype=torch.float32, device=dev)
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
         d = _lib.BnBwdDesc()
@@ -125,9 +134,12 @@ class BatchNormAct(torch.autograd.Function):
         d.dx, d.dx_stride = dx.data_ptr(), dx.stride(0)
         d.dgamma, d.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
         d.stat_slot = slot.data_ptr()
+        if rbuf is not None:
+            d.residual_grad, d.rg_stride = rbuf.data_ptr(), rbuf.stride(0)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_bwd")
-        return dx, dgb[0], dgb[1], (dz if ctx.has_res else None), None, None, None, None, None, None, None
+        gres = None if (not ctx.has_res or rbuf is not None) else dz
+        return dx, dgb[0], dgb[1], gres, None, None, None, None, None, None, None, None
 
 
 _LIN_WIDTHS = (32, 64, 96, 104, 128)   # lin_fused.h: fully unrolled k-loops
@@ -210,7 +222,7 @@ def linear(x, lin):
     return lin(x)
 
 
-def batch_norm_act(x, bn, relu=False, residual=None):
+def batch_norm_act(x, bn, relu=False, residual=None, out=None):
     """nn.BatchNorm1d `bn` applied to x [N,C] (+ReLU) (+residual).  Training mode with batch statistics runs
     on the HIP kernels; everything else (eval, no affine, cumulative momentum, C > 256) on torch's GPU op."""
     use_hip = (bn.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and bn.affine
@@ -219,7 +231,7 @@ def batch_norm_act(x, bn, relu=False, residual=None):
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
         nbt = bn.num_batches_tracked if bn.track_running_stats else None   # incremented inside the stats kernel
         return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt,
-                                  _column_stats_of(x))
+                                  _column_stats_of(x), out)
     out = bn(x)
     if relu:
         out = F.relu(out)
@@ -355,6 +367,54 @@ def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False):
         return z
     h = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
     return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)
+
+
+# ------------------------------------------------------------------------------------ jumping-knowledge projection
+class JKConcatLinear(torch.autograd.Function):
+    """relu(cat(states, dim=1) W^T + b) for states that already LIVE side by side in one [N, S*H] buffer (the producers
+    wrote their rows there: ops.rows_of / OutRows), so the reference's torch.cat of all layer outputs
+    (models/GNNs.py:216-218, 177 MB copied per step at B = 2048) never happens.  A state that is not the expected slice
+    is copied in.  Backward: one GEMM gives all S input gradients as the slices of one [N, S*H] buffer; a state whose
+    gradient is being collected in a cell (ops.state_cell: GNNPlus' hop-slot history) gets its slice PARKED there -
+    the layers' gather kernels and the norms' residual branches then add into it in place and the state's last reader
+    hands autograd the total, instead of autograd summing S + 2 tensors per state."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, buf, H, *states):
+        cells = []
+        for l, st in enumerate(states):
+            sl = buf[:, l * H:(l + 1) * H]
+            if st.data_ptr() == sl.data_ptr() and tuple(st.stride()) == tuple(sl.stride()) and tuple(st.shape) == tuple(sl.shape):
+                cells.append(getattr(st, "_kp_slot_cell", None))
+            else:
+                sl.copy_(st)
+                cells.append(None)
+        y = torch.addmm(bias, buf, weight.t()) if bias is not None else buf @ weight.t()
+        y.relu_()
+        ctx.save_for_backward(weight, buf, y)
+        ctx.cells, ctx.H, ctx.has_bias = cells, H, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, buf, y = ctx.saved_tensors
+        H = ctx.H
+        dym = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
+        G = dym @ weight                                  # [N, S*H]: every state's gradient, side by side
+        dw = dym.t() @ buf if ctx.needs_input_grad[0] else None
+        db = dym.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        grads = []
+        for l, cell in enumerate(ctx.cells):
+            if not ctx.needs_input_grad[4 + l]:
+                grads.append(None)
+                continue
+            gl = G[:, l * H:(l + 1) * H]
+            if cell is not None and cell.buf is None:
+                cell.buf = gl                             # parked: the state's remaining readers add to it in place
+                grads.append(None)
+            else:
+                grads.append(gl)
+        return (dw, db, None, None, *grads)
 
 
 # ------------------------------------------------------------------- KP-GIN per-hop MLP (+ geometric combine + projection)

@@ -856,7 +856,7 @@ def _gpu_relu_masks(node):
 
 
 @pytest.mark.parametrize("N,I,O", [(4099, 104, 104), (1500, 64, 104), (47450, 104, 104), (33, 32, 32), (2048, 96, 96),
-                                   (2500, 128, 128), (1000, 104, 64), (32768, 104, 104), (2, 32, 32)])
+                                   (2500, 128, 128), (1000, 104, 64), (32768, 104, 104), (17, 32, 32)])
 @pytest.mark.parametrize("follow_norm", [False, True])
 def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     """kpgnn_linear_bn + slots: Linear-BN-ReLU-Linear-BN-ReLU (KPGINplus.py:25-30) in 3 + 5 launches against the same
