@@ -328,7 +328,11 @@ class KHopAggregate(torch.autograd.Function):
         ctx.n_slots = len(xs)
         if xs:   # per-hop inputs: k separate [N,D] states instead of one stacked [N,k,D] tensor
             assert x is None and len(xs) == k_act
-            xs = [t.float().contiguous() for t in xs]
+            xs = [t.float() for t in xs]
+            # the kernel reads every hop slot with ONE row stride (x_sn): row-strided slots (column slices of the bodies'
+            # jumping-knowledge buffer) are read where they are; only mixed layouts are copied
+            if any(t.stride(1) != 1 for t in xs) or len({t.stride(0) for t in xs}) != 1:
+                xs = [t.contiguous() for t in xs]
         else:
             x = _last_contig(x.float())
         if periph is not None:
