@@ -372,6 +372,11 @@ typedef struct kpgnn_linear_desc {
     const float* bias;                    /* device [O] or NULL */
     float* y; int64_t y_stride;           /* device [N,O] */
     int32_t w_transposed;                 /* 1: w is [I,O] (y = x w): dx = dy W needs no transposed copy of W */
+    /* Optional blocked output (O > 128 only): output column o is written to block o / y_block_cols, column
+     * o % y_block_cols, i.e. y is [O / y_block_cols][N][y_block_cols] with y_stride = y_block_cols and the blocks
+     * y_block_stride floats apart.  The input gradient of a jumping-knowledge projection (models/GNNs.py:216-218) then
+     * comes out as one contiguous [N,H] matrix per layer state instead of [N, S*H] column slices.  0: plain [N,O]. */
+    int32_t y_block_cols; int64_t y_block_stride;
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);

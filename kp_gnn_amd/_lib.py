@@ -126,7 +126,7 @@ class LinearDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("x", c_vp), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64),
-        ("w_transposed", c_i32),
+        ("w_transposed", c_i32), ("y_block_cols", c_i32), ("y_block_stride", c_i64),
     ]
 
 

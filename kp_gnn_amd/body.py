@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
-from .ops import DictPeripheral, embedding_rows, rows_of, segment_pool, table_gather_sum
+from .ops import DictPeripheral, embedding_rows, segment_pool, table_gather_sum
 from .ops_dense import JKConcatLinear, batch_norm_act
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
@@ -97,10 +97,9 @@ class EmbeddingEncoder(nn.Module):
     def reset_parameters(self):
         self.init_proj.reset_parameters()
 
-    def forward(self, data, out=None):
-        """out: optional ops.OutRows - the rows are written there (a slice of the bodies' jumping-knowledge buffer)."""
+    def forward(self, data):
         if data.x.is_cuda:   # (host-sync-free backward: hipGraph-capturable, unlike nn.Embedding's)
-            return embedding_rows(self.init_proj.weight, data.x, out=out)
+            return embedding_rows(self.init_proj.weight, data.x)
         return self.init_proj(data.x)
 
 
@@ -177,8 +176,8 @@ class BatchNorm(nn.Module):
     def reset_parameters(self):
         self.module.reset_parameters()
 
-    def forward(self, x, residual=None, out=None):
-        return batch_norm_act(x, self.module, relu=False, residual=residual, out=out)
+    def forward(self, x, residual=None):
+        return batch_norm_act(x, self.module, relu=False, residual=residual)
 
 
 def _vn_mlp(h):
@@ -249,31 +248,12 @@ class _KHopBody(nn.Module):
             nn.init.normal_(self.pcw)
 
     # -- pieces of forward
-    def _inputs(self, data, out=None):
-        rd = _get(data, "rd")
-        plain = isinstance(self.init_proj, EmbeddingEncoder) and not (self.use_rd and rd is not None)
-        if out is not None and plain and data.x.is_cuda and data.x.numel() == out.t.shape[0]:
-            return self.init_proj(data, out=out)       # the embedding rows land in slice 0 of the jumping-knowledge buffer
+    def _inputs(self, data):
         x = self.init_proj(data).squeeze()
+        rd = _get(data, "rd")
         if self.use_rd and rd is not None:
             x = x + self.rd_projection(rd).squeeze()
         return x
-
-    def _jk_buffer(self, data):
-        """[N, (L+1)*H] buffer whose column slices ARE the states h_0 .. h_L (each producer writes its rows there), for
-        JK = "concat" on the HIP training path; None otherwise (the states are then ordinary tensors and _jk concatenates).
-        Needs every state to come straight out of a kernel that can write strided rows: no dropout mask and no
-        virtual-node add between a layer's norm and the next layer."""
-        x = data.x
-        ok = (self.JK == "concat" and x.is_cuda and self.training and torch.is_grad_enabled() and not self.virtual_node
-              and self.dropout.p == 0.0 and self.hidden_size % 4 == 0)
-        if not ok:
-            return None
-        n = x.shape[0]
-        return torch.empty((n, (self.num_layer + 1) * self.hidden_size), dtype=torch.float32, device=x.device)
-
-    def _rows(self, jk, l):
-        return None if jk is None else rows_of(jk, l * self.hidden_size, self.hidden_size)
 
     def _peripheral(self, data, num_nodes, like):
         """Peripheral-subgraph features P [N,K,width] (GNNs.py:171-179 / :392-400 / :636-644).
@@ -316,10 +296,10 @@ class _KHopBody(nn.Module):
         upd = self.dropout(self.mlp_virtualnode_list[l](tmp))
         return vn + upd if self.residual else upd
 
-    def _jk(self, h_list, jk=None):
-        if self.JK == "concat" and jk is not None:
+    def _jk(self, h_list):
+        if self.JK == "concat" and h_list[0].is_cuda and h_list[0].dtype == torch.float32 and torch.is_grad_enabled():
             lin = self.output_proj[0]
-            return self.output_proj[2](JKConcatLinear.apply(lin.weight, lin.bias, jk, self.hidden_size, *h_list))
+            return self.output_proj[2](JKConcatLinear.apply(lin.weight, lin.bias, *h_list))
         if self.JK == "concat":
             rep = torch.cat(h_list, dim=1)
         elif self.JK == "last":
@@ -359,8 +339,7 @@ class GNN(_KHopBody):
     def forward(self, data):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
-        jk = self._jk_buffer(data)
-        x = self._inputs(data, self._rows(jk, 0))
+        x = self._inputs(data)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list = [x]
@@ -370,7 +349,7 @@ class GNN(_KHopBody):
             # norm (+ residual) in one pass whenever no dropout mask sits between them (as in GNNPlus below)
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
             h = self.norms[l](self.gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph),
-                              residual=h_list[l] if fuse_res else None, out=self._rows(jk, l + 1))
+                              residual=h_list[l] if fuse_res else None)
             if l != self.num_layer - 1:
                 h = self.dropout(h)
             if self.residual and not fuse_res:
@@ -378,7 +357,7 @@ class GNN(_KHopBody):
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:
                 vn = self._vn_update(l, vn, h_list[l], batch)
-        return self._jk(h_list, jk)
+        return self._jk(h_list)
 
 
 class GNNPlus(_KHopBody):
@@ -406,8 +385,7 @@ class GNNPlus(_KHopBody):
     def forward(self, data):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
-        jk = self._jk_buffer(data)
-        x = self._inputs(data, self._rows(jk, 0))
+        x = self._inputs(data)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list, last_h = [x], x
@@ -423,7 +401,7 @@ class GNNPlus(_KHopBody):
             else:
                 h = self.gnns[l](torch.stack(slots, dim=1), edge_index, edge_attr[:, :k], pek, periph[:, :k])
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
-            h = self.norms[l](h, residual=last_h if fuse_res else None, out=self._rows(jk, l + 1))   # norm (+ residual) in one pass
+            h = self.norms[l](h, residual=last_h if fuse_res else None)   # norm (+ residual) in one pass
             if l != self.num_layer - 1:
                 h = self.dropout(h)
             if self.residual:
@@ -433,7 +411,7 @@ class GNNPlus(_KHopBody):
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:
                 vn = self._vn_update(l, vn, h_list[l], batch)
-        return self._jk(h_list, jk)
+        return self._jk(h_list)
 
 
 class GNNPrime(_KHopBody):
@@ -465,8 +443,7 @@ class GNNPrime(_KHopBody):
     def forward(self, data):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
-        jk = self._jk_buffer(data)
-        x = self._inputs(data, self._rows(jk, 0))
+        x = self._inputs(data)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list = [x]
@@ -479,7 +456,7 @@ class GNNPrime(_KHopBody):
                 h = self.gins[l - self.num_l1_layer](h_list[l], edge_index, edge_attr[:, :1])
             drops = l < self.num_l1_layer or l != self.num_layer - 1   # (:659 drops out after every K-hop layer)
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or not drops)
-            h = self.norms[l](h, residual=h_list[l] if fuse_res else None, out=self._rows(jk, l + 1))
+            h = self.norms[l](h, residual=h_list[l] if fuse_res else None)
             if drops:
                 h = self.dropout(h)
             if self.residual and not fuse_res:
@@ -487,7 +464,7 @@ class GNNPrime(_KHopBody):
             h_list.append(h)
             if self.virtual_node and l < self.num_layer - 1:
                 vn = self._vn_update(l, vn, h_list[l], batch)
-        return self._jk(h_list, jk)
+        return self._jk(h_list)
 
 
 def make_GNN(args):

@@ -199,6 +199,7 @@ struct LinParams {
     const float* x; int64_t xs;
     const float* w; const float* bias;
     float* y; int64_t ys;
+    int yb; int64_t ybs;   // wide kernel: output column o lands in block o / yb at column o % yb; blocks are ybs floats apart (yb == O: plain rows)
 };
 
 // Wide outputs (O > 128, e.g. the input gradient of the jumping-knowledge projection: [N,104] x [104,936]): the x tile
@@ -273,7 +274,7 @@ linear_wide_kernel(const LinParams p) {
                     for (int m = 0; m < M; ++m) {
                         const int64_t r = r0 + m * 32 + c;
                         if (r < p.N)
-                            *reinterpret_cast<float4*>(p.y + r * p.ys + ob) =
+                            *reinterpret_cast<float4*>(p.y + (int64_t)(ob / p.yb) * p.ybs + r * p.ys + (ob % p.yb)) =
                                 make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
                     }
                 }
@@ -290,7 +291,12 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_fwd: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
     if (d->O > 4096 || d->I > 128) return fail(KPGNN_ELIMIT, "linear_fwd: O=%d exceeds 4096 or I=%d exceeds 128", d->O, d->I);
     KPGNN_REQUIRE(d->x && d->w && d->y, "linear_fwd: NULL pointer");
-    if ((d->O % 4) != 0 || (d->I % 4) != 0 || d->x_stride != d->I || d->y_stride != d->O ||
+    const bool blocked = d->y_block_cols > 0 && d->y_block_cols < d->O;   // output split into column blocks ([S, N, yb] layout)
+    if (blocked && ((d->y_block_cols % 4) != 0 || (d->O % d->y_block_cols) != 0 || d->y_stride != d->y_block_cols ||
+                    (d->y_block_stride % 4) != 0 || d->O <= 128))
+        return fail(KPGNN_ELIMIT, "linear_fwd: blocked output needs O > 128, O %% y_block_cols == 0, y_block_cols %% 4 == 0, "
+                                  "y_stride == y_block_cols and a 16-B aligned block stride");
+    if ((d->O % 4) != 0 || (d->I % 4) != 0 || d->x_stride != d->I || (!blocked && d->y_stride != d->O) ||
         (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
         return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
@@ -306,6 +312,7 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const int rowp = d->I + ((4 - d->I % 8) + 8) % 8;   // pitch = 4 (mod 8) floats: 16-B aligned rows, conflict-free 16-B accesses
     p.pitch = rowp; p.ypitch = rowp;
     p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
+    p.yb = blocked ? d->y_block_cols : d->O; p.ybs = blocked ? d->y_block_stride : 0;
     // rows per tile = 32 * m, m in 1..3, the smallest that makes the launch one round over two blocks per CU
     const int64_t slots = (int64_t)device_facts().cu_count * 2;
     int m = (int)((d->N + slots * 32 - 1) / (slots * 32));

@@ -528,18 +528,14 @@ class TableGatherSum(torch.autograd.Function):
     """out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :]  (kpgnn_table_gather_sum_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, table, bias, idx, col_offset, out=None):
+    def forward(ctx, table, bias, idx, col_offset):
         _require_cuda(table, bias, idx, col_offset)
         lib = _lib.load()
         table = table.contiguous()
         bias = bias.contiguous() if bias is not None else None
         M, C = idx.shape
         R, D = table.shape
-        if out is None:
-            out = torch.empty((M, D), dtype=torch.float32, device=table.device)
-        else:   # OutRows: caller-provided storage for the result (rows of a wider buffer)
-            out = out.t
-            assert tuple(out.shape) == (M, D) and out.stride(1) == 1 and out.dtype == torch.float32 and out.grad_fn is None
+        out = torch.empty((M, D), dtype=torch.float32, device=table.device)
         d = _lib.TgsDesc()
         d.M, d.C, d.D, d.R = M, C, D, R
         d.idx, d.col_offset, d.table, d.bias = idx.data_ptr(), col_offset.data_ptr(), table.data_ptr(), _ptr(bias)
@@ -569,24 +565,7 @@ class TableGatherSum(torch.autograd.Function):
         with torch.cuda.device(gout.device):
             _lib.check(lib.kpgnn_table_gather_sum_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_table_gather_sum_bwd")
         gbias = gout.sum(0) if ctx.has_bias else None
-        return gtable, gbias, None, None, None
-
-
-class OutRows:
-    """Storage an operator should write its [M, D] result to instead of allocating: `rows_of(buf, col0, D)` of a wider
-    row-major buffer.  Handed to autograd Functions as a non-tensor argument: the tensor inside has no history and is no
-    registered view of the buffer (Tensor.set_), so the operator's output is an ordinary fresh tensor for autograd."""
-    __slots__ = ("t",)
-
-    def __init__(self, t):
-        self.t = t
-
-
-def rows_of(buf, col0, D):
-    """OutRows over columns [col0, col0 + D) of the 2-D row-major buffer `buf`."""
-    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
-    t.set_(buf.untyped_storage(), buf.storage_offset() + col0, (buf.shape[0], D), (buf.stride(0), 1))
-    return OutRows(t)
+        return gtable, gbias, None, None
 
 
 def table_gather_sum(table, bias, idx, col_offset):
@@ -612,7 +591,7 @@ class _ZeroRowGrad(torch.autograd.Function):
         return g, None
 
 
-def embedding_rows(weight, idx, padding_idx=None, out=None):
+def embedding_rows(weight, idx, padding_idx=None):
     """weight[idx] for an integer index tensor of any shape (the bodies' input embedding, input_encoder.py:21-22; the
     layers' path encoding, KPGIN.py:92-93) through the gather-sum kernels: unlike the framework's embedding backward
     (sort + unique_by_key with a host read-back, which FAULTS when a captured hipGraph replays it) this is free of
@@ -645,8 +624,6 @@ def embedding_rows(weight, idx, padding_idx=None, out=None):
             pass
     if padding_idx is not None and weight.requires_grad:
         weight = _ZeroRowGrad.apply(weight, int(padding_idx))
-    if out is not None:      # [M, D] rows of a caller-provided (possibly strided) buffer
-        return TableGatherSum.apply(weight, None, rec[1], rec[2], out)
     res = TableGatherSum.apply(weight, None, rec[1], rec[2])
     return res.view(*idx.shape, weight.shape[1])
 

@@ -81,18 +81,13 @@ def _column_stats_of(t):
 
 class BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None, ready_slot=None,
-                out=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, nbt=None, ready_slot=None):
         lib = _lib.load()
         x = x if x.stride(-1) == 1 else x.contiguous()
         N, C = x.shape
         dev = x.device
         slot = ready_slot if ready_slot is not None else take_stat_slot(C, dev)
-        if out is None:
-            z = torch.empty((N, C), dtype=torch.float32, device=dev)
-        else:    # ops.OutRows: write the result into the caller's rows (a slice of the jumping-knowledge buffer)
-            z = out.t
-            assert tuple(z.shape) == (N, C) and z.stride(1) == 1 and z.grad_fn is None
+        z = torch.empty((N, C), dtype=torch.float32, device=dev)
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
@@ -139,7 +134,7 @@ class BatchNormAct(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(x)), "kpgnn_bn_bwd")
         gres = None if (not ctx.has_res or rbuf is not None) else dz
-        return dx, dgb[0], dgb[1], gres, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], gres, None, None, None, None, None, None, None
 
 
 _LIN_WIDTHS = (32, 64, 96, 104, 128)   # lin_fused.h: fully unrolled k-loops
@@ -222,7 +217,7 @@ def linear(x, lin):
     return lin(x)
 
 
-def batch_norm_act(x, bn, relu=False, residual=None, out=None):
+def batch_norm_act(x, bn, relu=False, residual=None):
     """nn.BatchNorm1d `bn` applied to x [N,C] (+ReLU) (+residual).  Training mode with batch statistics runs
     on the HIP kernels; everything else (eval, no affine, cumulative momentum, C > 256) on torch's GPU op."""
     use_hip = (bn.training and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and bn.affine
@@ -231,7 +226,7 @@ def batch_norm_act(x, bn, relu=False, residual=None, out=None):
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
         nbt = bn.num_batches_tracked if bn.track_running_stats else None   # incremented inside the stats kernel
         return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt,
-                                  _column_stats_of(x), out)
+                                  _column_stats_of(x))
     out = bn(x)
     if relu:
         out = F.relu(out)
@@ -371,50 +366,64 @@ def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False):
 
 # ------------------------------------------------------------------------------------ jumping-knowledge projection
 class JKConcatLinear(torch.autograd.Function):
-    """relu(cat(states, dim=1) W^T + b) for states that already LIVE side by side in one [N, S*H] buffer (the producers
-    wrote their rows there: ops.rows_of / OutRows), so the reference's torch.cat of all layer outputs
-    (models/GNNs.py:216-218, 177 MB copied per step at B = 2048) never happens.  A state that is not the expected slice
-    is copied in.  Backward: one GEMM gives all S input gradients as the slices of one [N, S*H] buffer; a state whose
-    gradient is being collected in a cell (ops.state_cell: GNNPlus' hop-slot history) gets its slice PARKED there -
-    the layers' gather kernels and the norms' residual branches then add into it in place and the state's last reader
-    hands autograd the total, instead of autograd summing S + 2 tensors per state."""
+    """relu(cat(states, dim=1) W^T + b): the bodies' jumping-knowledge projection (models/GNNs.py:216-218, output_proj).
+    Forward is the reference's concat + one GEMM.  Backward: the input gradient dY W of all S states comes out of ONE
+    launch as S contiguous [N,H] matrices (kpgnn_linear_fwd with a blocked output: 118 us against the BLAS library's
+    146 us for [47k,104] x [104,936]), and a state whose gradient is being collected in a cell (ops.state_cell: GNNPlus'
+    hop-slot history) gets its matrix PARKED there - the layers' gather kernels and the norms' residual branches then
+    add into it in place and the state's last reader hands autograd the total, instead of autograd summing S + 2
+    strided tensors per state (36 adds of ~20 MB per step at K = L = 8)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, buf, H, *states):
-        cells = []
-        for l, st in enumerate(states):
-            sl = buf[:, l * H:(l + 1) * H]
-            if st.data_ptr() == sl.data_ptr() and tuple(st.stride()) == tuple(sl.stride()) and tuple(st.shape) == tuple(sl.shape):
-                cells.append(getattr(st, "_kp_slot_cell", None))
-            else:
-                sl.copy_(st)
-                cells.append(None)
-        y = torch.addmm(bias, buf, weight.t()) if bias is not None else buf @ weight.t()
+    def forward(ctx, weight, bias, *states):
+        rep = torch.cat(states, dim=1)
+        y = torch.addmm(bias, rep, weight.t()) if bias is not None else rep @ weight.t()
         y.relu_()
-        ctx.save_for_backward(weight, buf, y)
-        ctx.cells, ctx.H, ctx.has_bias = cells, H, bias is not None
+        ctx.save_for_backward(weight, rep, y)
+        ctx.cells = [getattr(st, "_kp_slot_cell", None) for st in states]
+        ctx.widths = [st.shape[1] for st in states]
+        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        weight, buf, y = ctx.saved_tensors
-        H = ctx.H
+        weight, rep, y = ctx.saved_tensors
+        S, H = len(ctx.widths), ctx.widths[0]
+        N, O = y.shape
         dym = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
-        G = dym @ weight                                  # [N, S*H]: every state's gradient, side by side
-        dw = dym.t() @ buf if ctx.needs_input_grad[0] else None
+        dw = dym.t() @ rep if ctx.needs_input_grad[0] else None
         db = dym.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        parts = None
+        if (all(w == H for w in ctx.widths) and S * H > 128 and H % 4 == 0 and O in (32, 64, 104, 128) and weight.is_contiguous()
+                and dym.data_ptr() % 16 == 0):
+            lib = _lib.load()
+            G = torch.empty((S, N, H), dtype=torch.float32, device=dy.device)
+            d = _lib.LinearDesc()
+            d.N, d.O, d.I = N, S * H, O
+            d.x, d.x_stride, d.w, d.y, d.y_stride = dym.data_ptr(), O, weight.data_ptr(), G.data_ptr(), H
+            d.w_transposed, d.y_block_cols, d.y_block_stride = 1, H, N * H
+            with torch.cuda.device(dy.device):
+                rc = lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(dym))
+            if rc == 0:
+                parts = [G[l] for l in range(S)]
+            elif rc != -3:
+                _lib.check(rc, "kpgnn_linear_fwd")
+        if parts is None:
+            G = dym @ weight
+            parts, c0 = [], 0
+            for w in ctx.widths:
+                parts.append(G[:, c0:c0 + w])
+                c0 += w
         grads = []
         for l, cell in enumerate(ctx.cells):
-            if not ctx.needs_input_grad[4 + l]:
+            if not ctx.needs_input_grad[2 + l]:
                 grads.append(None)
-                continue
-            gl = G[:, l * H:(l + 1) * H]
-            if cell is not None and cell.buf is None:
-                cell.buf = gl                             # parked: the state's remaining readers add to it in place
+            elif cell is not None and cell.buf is None and parts[l].is_contiguous():
+                cell.buf = parts[l]                       # parked: the state's remaining readers add to it in place
                 grads.append(None)
             else:
-                grads.append(gl)
-        return (dw, db, None, None, *grads)
+                grads.append(parts[l])
+        return (dw, db, *grads)
 
 
 # ------------------------------------------------------------------- KP-GIN per-hop MLP (+ geometric combine + projection)
