@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py - graphs/s of the KP-GIN+ training step (fwd + bwd + Adam) on ZINC-12k-shaped synthetic batches.
+"""bench.py - throughput of the K-hop message-passing hot path on synthetic batches of the reference's shapes.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--model KPGINPlus|KPGIN] [--combine geometric|attention]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload zinc|qm9|regular|zinc_gd16] [--batch B]
+                    [--model KPGINPlus|KPGIN] [--combine geometric|attention] [--dense-peripheral]
 
-Workload (BASELINE.json configs[1], reference README.md:127 `train_ZINC.py --residual --K=8 --model_name=KPGINPlus
---num_layer=8 --hidden_size=104`): GNNPlus body, K=8, L=8, h=104, geometric combine, JK=concat, BatchNorm, sum
-pooling, L1 loss, Adam; synthetic molecule graphs of ZINC-12k's shape (kpgnn_host.h, ~23 nodes / ~500 K=8-spd
-edges per graph), exact K-hop pre-transform by libkpgnn_host.so, random-init weights (seed 0).
-A "step" is one optimisation step on one pre-staged batch of B graphs per GPU (inputs and the K-hop CSR
-resident in HBM before the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
-ranks, model replicated, one RCCL all-reduce (mean) of the flat gradient bucket per step; weak scaling.
+Default workload = BASELINE.json configs[1] (reference README.md:127 `train_ZINC.py --residual --K=8
+--model_name=KPGINPlus --num_layer=8 --hidden_size=104`): GNNPlus body, K=8, L=8, h=104, geometric combine, JK=concat,
+BatchNorm, sum pooling, L1 loss, Adam; synthetic molecule graphs of ZINC-12k's shape (kpgnn_host.h, ~23 nodes / ~500
+K=8-spd edges per graph), exact K-hop pre-transform by libkpgnn_host.so, random-init weights (seed 0).
+Other workloads (the configurations of BASELINE.json that are parity cases for the default line):
+  qm9        configs[2]: QM9-shaped molecules, KP-GIN (GNN body) K=6 L=8 h=120 spd, MSE loss, Adam (train_qm9.py:96,141-158)
+  regular    configs[3]: random 3-regular graphs n=1280, run_simulation.py's KGINConv(16, K=8), FORWARD ONLY (eval, no grad),
+             --batch graphs per step (the script uses 1; --batch 100 = its whole set of N=100 graphs at once)
+  zinc_gd16  configs[4]: KP-GIN' (GNNPrime: one KP-GIN layer + 16 GINE layers) K=16 L=17 h=96 kernel=gd, L1, Adam
+A "step" is one optimisation step (forward only for `regular`) on one pre-staged batch of B graphs per GPU (inputs and the
+K-hop CSR resident in HBM before the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
+ranks, model replicated, one RCCL all-reduce of the flat gradient bucket per step; weak scaling.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     HIP-event timing of the aggregation kernel launches inside the timed region vs the
-                  algorithmic bytes of SURVEY.md 8(d) (HBM bound, peak 8 TB/s);
-  "cpu_baseline": the oracle ("port": oracle/kp_model_oracle.py, the reference's materialised [E,K,D] op
-                  sequence in plain PyTorch) timed on this box's host cores on a bounded sample.
+  "roofline":     HIP-event timing of the aggregation kernel launches vs the algorithmic bytes of SURVEY.md 8(d)
+                  (HBM bound, peak 8 TB/s), with the workload's own A and D;
+  "cpu_baseline": the oracle ("port": oracle/, the reference's materialised [E,K,D] op sequence in plain PyTorch)
+                  timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,7 +33,6 @@ import time
 import torch
 
 dp = None
-ops_dense = None
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -40,26 +46,61 @@ def log(msg):
 
 from kp_gnn_amd._env import usable_cpus  # noqa: E402
 
+# workload -> defaults.  metric: the JSON's "metric" string (the default line carries BASELINE.json's).
+WORKLOADS = {
+    "zinc": dict(model="KPGINPlus", K=8, layers=8, hidden=104, batch=2048, kernel="spd", loss="l1", train=True,
+                 metric="graphs/sec KP-GIN fwd+bwd, ZINC-12k K=8 L=8 h=104"),
+    "qm9": dict(model="KPGIN", K=6, layers=8, hidden=120, batch=128, kernel="spd", loss="mse", train=True,
+                metric="graphs/sec KP-GIN fwd+bwd, QM9-shaped K=6 L=8 h=120"),
+    "regular": dict(model="KGIN", K=8, layers=1, hidden=16, batch=1, kernel="spd", loss=None, train=False,
+                    metric="graphs/sec KGINConv forward, 3-regular n=1280 K=8 h=16 (run_simulation.py)"),
+    "zinc_gd16": dict(model="KPGINPrime", K=16, layers=17, hidden=96, batch=2048, kernel="gd", loss="l1", train=True,
+                      metric="graphs/sec KP-GIN' fwd+bwd, ZINC-12k K=16 L=17 h=96 gd"),
+}
+
+
+def make_batch(args, seed0, threads):
+    from kp_gnn_amd import batch as KB
+    if args.workload == "qm9":
+        return KB.synthetic_qm9_batch(args.batch, seed0=seed0, K=args.K, kernel=args.kernel, num_threads=threads)
+    if args.workload == "regular":
+        return KB.synthetic_regular_batch(args.batch, seed0=seed0, n=1280, degree=3, K=args.K, num_threads=threads)
+    return KB.synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K, kernel=args.kernel, num_threads=threads)
+
 
 def build_model(args, device):
     from kp_gnn_amd import body as B
-    from kp_gnn_amd.layers import make_gnn_layer
-    ns = argparse.Namespace(model_name=args.model, hidden_size=args.hidden, K=args.K, num_layer=args.layers,
-                            num_hop1_edge=3, max_pe_num=50, combine=args.combine, eps=0., train_eps=False, aggr="add")
+    from kp_gnn_amd.layers import KGINConv, make_gnn_layer
     torch.manual_seed(0)
+    if args.workload == "regular":
+        return KGINConv(args.hidden, args.K).to(device).eval()          # run_simulation.py:104-107,133
+    qm9 = args.workload == "qm9"
+    ns = argparse.Namespace(model_name=args.model, hidden_size=args.hidden, K=args.K, num_layer=args.layers,
+                            num_hop1_edge=4 if qm9 else 3, max_pe_num=50, combine=args.combine, eps=0., train_eps=False,
+                            aggr="add")
+    enc = B.QM9InputEncoder(args.hidden) if qm9 else B.EmbeddingEncoder(21, args.hidden)
+    kw = dict(max_edge_count=20, max_hop_num=5, max_distance_count=15) if qm9 else \
+        dict(max_edge_count=50, max_hop_num=6, max_distance_count=50)
     gnn = B.make_GNN(ns)(num_layer=args.layers, gnn_layer=make_gnn_layer(ns), JK="concat", norm_type="Batch",
-                         init_emb=B.EmbeddingEncoder(21, args.hidden), residual=True, virtual_node=False, use_rd=False,
-                         num_hop1_edge=3, max_edge_count=50, max_hop_num=6, max_distance_count=50,
-                         wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.0)
+                         init_emb=enc, residual=not qm9, virtual_node=False, use_rd=False, num_hop1_edge=ns.num_hop1_edge,
+                         wo_peripheral_edge=False, wo_peripheral_configuration=False, drop_prob=0.0, **kw)
     model = B.GraphRegression(gnn, "sum")
     return model.to(device).train()
 
 
-def fwd_bwd(model, batch, flat_grad):
+def loss_of(args, score, y):
+    d = score.squeeze() - y.squeeze()
+    return d.abs().mean() if args.loss == "l1" else (d * d).mean()       # train_ZINC.py:42 / train_qm9.py:96
+
+
+def fwd_bwd(args, model, batch, flat_grad):
     """Forward + backward; the parameter gradients land in the flat bucket with ONE multi-tensor copy (autograd.grad
-    returns them instead of running ~190 per-parameter accumulate kernels into pre-zeroed .grad views)."""
-    score = model(batch)
-    loss = (score.squeeze() - batch.y.squeeze()).abs().mean()  # train_ZINC.py:42
+    returns them instead of running ~190 per-parameter accumulate kernels into pre-zeroed .grad views).
+    Forward-only workloads (`regular`) just run the layer as the reference's script does (eval, no grad)."""
+    if not args.train:
+        with torch.no_grad():
+            return model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    loss = loss_of(args, model(batch), batch.y)
     params, views = dp.grad_views(model)
     grads = torch.autograd.grad(loss, params, allow_unused=True)
     used = [(v, g) for v, g in zip(views, grads) if g is not None]
@@ -69,38 +110,29 @@ def fwd_bwd(model, batch, flat_grad):
     return loss
 
 
-def train_step(model, batch, opt, flat_grad, world, graph=None):
-    """One optimisation step.  With `graph` (a captured hipGraph of fwd+bwd on this batch's static tensors) the
-    ~1,500 launches of forward+backward replay as one graph launch; the gradient all-reduce and the fused Adam
-    step stay eager (a collective inside a captured graph is the one thing that cannot be rehearsed on 1 GPU)."""
-    trace = os.environ.get("KPGNN_BENCH_TRACE") == "1"
-    if trace:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+def train_step(args, model, batch, opt, flat_grad, world, graph=None):
+    """One step.  With `graph` (a captured hipGraph of fwd+bwd on this batch's static tensors) the launches of
+    forward+backward replay as one graph launch; the gradient all-reduce and the fused Adam step stay eager (a
+    collective inside a captured graph is the one thing that cannot be rehearsed on 1 GPU)."""
     if graph is not None:
         graph[0].replay()
-        loss = graph[1]
+        out = graph[1]
     else:
-        loss = fwd_bwd(model, batch, flat_grad)
-    if trace:
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-    dp.allreduce_mean(flat_grad, world)
-    if trace:
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-    opt.step()
-    if trace:
-        torch.cuda.synchronize(); t3 = time.perf_counter()
-        log(f"step phases: fwd+bwd {1e3*(t1-t0):.1f} ms, all-reduce {1e3*(t2-t1):.1f} ms, optimizer {1e3*(t3-t2):.1f} ms")
-    return loss
+        out = fwd_bwd(args, model, batch, flat_grad)
+    if args.train:
+        dp.allreduce_mean(flat_grad, world)
+        opt.step()
+    return out
 
 
-def capture_graphs(model, batches, flat_grad):
+def capture_graphs(args, model, batches, flat_grad):
     """hipGraph capture of fwd+bwd, one graph per pre-staged batch (shapes differ between batches)."""
     graphs = []
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for b in batches:                      # warm every batch on the side stream (allocator, caches)
-            fwd_bwd(model, b, flat_grad)
+            fwd_bwd(args, model, b, flat_grad)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     pool = None
@@ -110,61 +142,81 @@ def capture_graphs(model, batches, flat_grad):
     for b in batches:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-            loss = fwd_bwd(model, b, flat_grad)
+            out = fwd_bwd(args, model, b, flat_grad)
         pool = g.pool()
-        graphs.append((g, loss))
+        graphs.append((g, out))
     return graphs
+
+
+def csrc_digest():
+    """Hash of the kernel sources: a committed PMC traffic figure is only reported next to timings of the SAME kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kp_gnn_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the PMC counters.  A process cannot profile itself, so the figure comes
-    from the committed rocprofv3 --pmc passes of this same command (profiles/r01/pmc_traffic.json says how they were
-    collected and corrected) and is only reported when the workload is the one that was profiled; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
-    key = f"{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}"
+    from the committed rocprofv3 --pmc passes of this same command (profiles/r02/pmc_traffic.json says how they were
+    collected and corrected).  It is only reported when the workload AND the kernel sources (csrc digest) are the ones
+    that were profiled; otherwise null - a stale figure next to fresh timings would be worse than none."""
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    key = f"{args.workload}|{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}"
     try:
         with open(path) as fh:
             j = json.load(fh)
-        if j.get("workload_key") == key and kernel in j.get("kernels", {}):
+        if j.get("workload_key") == key and j.get("csrc_digest") == csrc_digest() and kernel in j.get("kernels", {}):
             return {"traffic": j["kernels"][kernel]["traffic_bytes_per_launch"],
-                    "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+                    "traffic_source": "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                      "this command on these kernel sources)"}
     except (OSError, ValueError):
         pass
     return {}
 
 
 def cpu_baseline(args, state_dict, threads):
-    """Oracle (CPU restatement of the reference path) fwd+bwd on a bounded sample of the same workload."""
-    from kp_gnn_amd.batch import synthetic_zinc_batch
+    """Oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+    from oracle import kp_layers_oracle as LO
     from oracle import kp_model_oracle as MO
     torch.set_num_threads(threads)
-    nb = args.cpu_graphs
-    b = synthetic_zinc_batch(nb, seed0=10_000_000, K=args.K)
+    saved = args.batch
+    args.batch = nb = min(args.cpu_graphs, saved) if args.workload != "regular" else 1
+    b = make_batch(args, 10_000_000, threads)
+    args.batch = saved
     data = b.as_dict()
-    kind, layer_kind = {"KPGINPlus": ("GNNPlus", "KPGINPlus"), "KPGIN": ("GNN", "KPGIN")}[args.model]
     p = {}
     for k, v in state_dict.items():
         v = v.detach().cpu().clone()
-        p[k] = v.requires_grad_(True) if (v.is_floating_point() and "running" not in k and not k.endswith(".eps")) else v
+        p[k] = v.requires_grad_(True) if (args.train and v.is_floating_point() and "running" not in k and not k.endswith(".eps")) else v
+    kind, layer_kind = {"KPGINPlus": ("GNNPlus", "KPGINPlus"), "KPGIN": ("GNN", "KPGIN"), "KPGINPrime": ("GNNPrime", "KPGIN"),
+                        "KGIN": (None, None)}[args.model]
     times = []
     for it in range(1 + args.cpu_iters):
         for v in p.values():
             if v.requires_grad:
                 v.grad = None
         t0 = time.perf_counter()
-        score = MO.graph_regression_forward(p, data, kind=kind, layer_kind=layer_kind, K=args.K, num_layer=args.layers,
-                                            combine_kind=args.combine, JK="concat", residual=True, training=True)
-        loss = (score.squeeze() - data["y"].squeeze()).abs().mean()
-        loss.backward()
+        if args.workload == "regular":
+            with torch.no_grad():
+                LO.kgin_forward(p, data["x"], data["edge_index"], data["edge_attr"], K=args.K)
+        else:
+            score = MO.graph_regression_forward(p, data, kind=kind, layer_kind=layer_kind, K=args.K, num_layer=args.layers,
+                                                combine_kind=args.combine, JK="concat", residual=args.workload != "qm9",
+                                                training=True)
+            loss_of(args, score, data["y"]).backward()
         dt = time.perf_counter() - t0
         log(f"  cpu iter {it}: {dt:.2f}s")
         if it > 0:
             times.append(dt)
     times.sort()
     med = times[len(times) // 2]
+    what = "forward (no grad)" if not args.train else "fwd+bwd, no optimizer step"
     return {"value": round(nb / med, 2), "unit": "graphs/s", "cores": threads, "kind": "port",
-            "sample": f"{nb} graphs x {args.cpu_iters} fwd+bwd iterations (median), oracle/kp_model_oracle.py, "
-                      f"torch {torch.__version__} CPU, no optimizer step"}
+            "sample": f"{nb} graphs x {args.cpu_iters} {what} iterations (median), oracle/, torch {torch.__version__} CPU"}
 
 
 def main():
@@ -172,13 +224,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=2048, help="graphs per GPU per step")
+    ap.add_argument("--workload", default="zinc", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU per step (default: the workload's)")
     ap.add_argument("--num-batches", type=int, default=4, help="distinct pre-staged batches cycled through")
-    ap.add_argument("--model", default="KPGINPlus", choices=("KPGINPlus", "KPGIN"))
+    ap.add_argument("--model", default=None, choices=("KPGINPlus", "KPGIN", "KPGINPrime"))
     ap.add_argument("--combine", default="geometric", choices=("geometric", "attention"))
-    ap.add_argument("--K", type=int, default=8)
-    ap.add_argument("--layers", type=int, default=8)
-    ap.add_argument("--hidden", type=int, default=104)
+    ap.add_argument("--K", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--dense-peripheral", action="store_true",
+                    help="hand the layers the dense [N,K,D] peripheral tensor instead of its dictionary form")
     ap.add_argument("--cpu-graphs", type=int, default=128)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,6 +243,13 @@ def main():
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    for k in ("model", "K", "layers", "hidden", "batch"):
+        if getattr(args, k) is None:
+            setattr(args, k, wl[k])
+    args.kernel, args.loss, args.train = wl["kernel"], wl["loss"], wl["train"]
+    if args.workload == "regular":
+        args.model = "KGIN"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -208,35 +270,39 @@ def main():
         else:
             torch.distributed.init_process_group("gloo")
 
+    from kp_gnn_amd import body as B
     from kp_gnn_amd import ops
-    from kp_gnn_amd.batch import synthetic_zinc_batch
-    global dp, ops_dense
-    from kp_gnn_amd import dp, ops_dense
+    global dp
+    from kp_gnn_amd import dp
+    if args.dense_peripheral:
+        B.MAX_DICT_ROWS = 0
 
     threads = max(1, usable_cpus() // max(1, min(world, 8)))
     torch.set_num_threads(threads)
     if rank == 0:
-        log(f"world={world} host threads/rank={threads} (os.cpu_count={os.cpu_count()})")
+        log(f"workload={args.workload} world={world} host threads/rank={threads} (os.cpu_count={os.cpu_count()})")
     t_data = time.perf_counter()
     batches = []
     for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
         seed0 = dp.shard_seed(rank, args.num_batches, i, args.batch)
-        b = synthetic_zinc_batch(args.batch, seed0=seed0, K=args.K, num_threads=threads).to(device)
+        b = make_batch(args, seed0, threads).to(device)
         b.build_csr()
         batches.append(b)
     torch.cuda.synchronize()
     t_data = time.perf_counter() - t_data
     if rank == 0:
         log(f"{args.num_batches} batches x {args.batch} graphs built + CSR on device in {t_data:.1f}s "
-            f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]})")
+            f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]}, A={batches[0].csr.A})")
 
     model = build_model(args, device)
-    if world > 1:  # identical replicas
-        dp.broadcast_model(model)
-    flat_grad = dp.flatten_grads(model)
-    flat_param = dp.flatten_params(model)     # parameters and gradients: one flat bucket each (same order)
-    flat_param.grad = flat_grad
-    opt = torch.optim.Adam([flat_param], lr=1e-3, fused=True, capturable=True)   # elementwise: identical to per-parameter Adam
+    flat_grad = opt = None
+    if args.train:
+        if world > 1:  # identical replicas
+            dp.broadcast_model(model)
+        flat_grad = dp.flatten_grads(model)
+        flat_param = dp.flatten_params(model)     # parameters and gradients: one flat bucket each (same order)
+        flat_param.grad = flat_grad
+        opt = torch.optim.Adam([flat_param], lr=1e-3, fused=True, capturable=True)   # elementwise: identical to per-parameter Adam
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,14 +311,14 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        train_step(model, batches[i % len(batches)], opt, flat_grad, world)
+        train_step(args, model, batches[i % len(batches)], opt, flat_grad, world)
     torch.cuda.synchronize()
     graphs = None
     if not args.no_graph:
         # (a capture failure is an error, not a silent downgrade to eager launches: --no-graph asks for those)
-        graphs = capture_graphs(model, batches, flat_grad)
+        graphs = capture_graphs(args, model, batches, flat_grad)
         for i in range(len(batches)):  # one replayed step per graph before timing
-            train_step(model, batches[i], opt, flat_grad, world, graphs[i])
+            train_step(args, model, batches[i], opt, flat_grad, world, graphs[i])
         torch.cuda.synchronize()
     if rank == 0:
         log(f"{args.warmup} warm-up steps done; launch mode: {'hipGraph replay' if graphs else 'eager'}")
@@ -260,11 +326,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         j = i % len(batches)
-        loss = train_step(model, batches[j], opt, flat_grad, world, graphs[j] if graphs else None)
+        out_t = train_step(args, model, batches[j], opt, flat_grad, world, graphs[j] if graphs else None)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(elapsed, device, world)
-    final_loss = float(loss.item())
+    final = float(out_t.float().abs().mean().item()) if not args.train else float(out_t.item())
     if rank == 0:
         log(f"timed {args.steps} steps in {elapsed:.3f}s")
     # Per-launch kernel timing (roofline leg): HIP events around every aggregation launch, on the launch
@@ -273,30 +339,35 @@ def main():
     if not args.no_roofline and rank == 0:
         timer = ops.LaunchTimer()
         ops.set_launch_timer(timer)
-        train_step(model, batches[0], opt, flat_grad, 1)  # primes the byte-accounting caches
+        train_step(args, model, batches[0], opt, flat_grad, 1)  # primes the byte-accounting caches
         timer.records.clear()
         for i in range(args.steps):
-            train_step(model, batches[i % len(batches)], opt, flat_grad, 1)
+            train_step(args, model, batches[i % len(batches)], opt, flat_grad, 1)
         torch.cuda.synchronize()
         ops.set_launch_timer(None)
 
     if rank == 0:
         total_graphs = args.batch * world * args.steps
         b0 = batches[0]
+        what = "fwd+bwd+Adam, " + ("L1" if args.loss == "l1" else "MSE") + " loss" if args.train else "forward only (eval, no grad)"
+        desc = {"zinc": "ZINC-12k-shaped synthetic molecules", "qm9": "QM9-shaped synthetic molecules",
+                "regular": "random 3-regular graphs n=1280", "zinc_gd16": "ZINC-12k-shaped synthetic molecules"}[args.workload]
         out = {
-            "metric": "graphs/sec KP-GIN fwd+bwd, ZINC-12k K=8 L=8 h=104",
+            "metric": wl["metric"] if (args.model == wl["model"] or args.workload == "zinc") else f"graphs/sec {args.model} {args.workload}",
             "value": round(total_graphs / elapsed, 1),
             "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ZINC-12k-shaped synthetic molecules, {args.model} K={args.K} L={args.layers} "
-                                   f"h={args.hidden} {args.combine} combine, fwd+bwd+Adam, L1 loss",
+            "config": {"workload": f"{desc}, {args.model} K={args.K} L={args.layers} h={args.hidden} kernel={args.kernel}"
+                                   + (f" {args.combine} combine" if args.train else "") + f", {what}"
+                                   + (", dense peripheral tensor" if args.dense_peripheral else ""),
                        "graphs_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.edge_index.shape[1]),
+                       "active_pairs_per_batch": int(b0.csr.A),
                        "parallelism": f"dp{world}", "launch": "hipGraph replay of fwd+bwd" if graphs else "eager",
-                       "final_loss": round(final_loss, 5),
+                       ("final_loss" if args.train else "mean_abs_output"): round(final, 5),
                        "data_build_s": round(t_data, 2)},
         }
         if timer is not None:
@@ -312,6 +383,15 @@ def main():
                 out["roofline"].update(pmc_traffic(args, "agg_fwd_kernel"))
             out["kernels"] = {k: {"launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                                   "algorithmic_GBps": round(v["gbps"], 1)} for k, v in s.items()}
+            big = [r for r in timer.records if r[0] == "agg_fwd"]
+            if big:   # the launch with the most algorithmic bytes (all K hops): its own roofline fraction
+                top = max(r[1] for r in big)
+                sel = [r for r in big if r[1] >= 0.999 * top]
+                ms = sum(a.elapsed_time(b) for _, _, a, b in sel) / len(sel)
+                out["kernels"]["agg_fwd_kmax"] = {"launches": len(sel), "avg_launch_ms": round(ms, 4),
+                                                  "algorithmic_bytes_per_launch": int(top),
+                                                  "algorithmic_GBps": round(top / (ms * 1e-3) / 1e9, 1),
+                                                  "frac": round(top / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             g = s.get("agg_bwd")
             if g:
                 out["roofline_bwd"] = {"bound": "hbm", "kernel": "agg_bwd_kernel", "achieved": round(g["gbps"], 1),
@@ -320,7 +400,7 @@ def main():
                                        "algorithmic_bytes_per_launch": int(g["bytes_per_launch"])}
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v for k, v in model.state_dict().items()}
-            log(f"cpu baseline: oracle on {threads} host threads, {args.cpu_graphs} graphs ...")
+            log(f"cpu baseline: oracle on {threads} host threads ...")
             out["cpu_baseline"] = cpu_baseline(args, sd, threads)
         print(json.dumps(out), flush=True)
     if world > 1:

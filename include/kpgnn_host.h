@@ -77,6 +77,19 @@ void kpgnn_khop_plan_destroy(kpgnn_khop_plan* plan);
 int kpgnn_synth_molecules(int64_t G, uint64_t seed0, int64_t* node_ptr, int64_t* edge_ptr, int64_t* edge_index,
                           int64_t* edge_attr, int64_t* atom_type);
 
+/* The same generator with the shape spelled out (NULL = the ZINC-12k shape above): node count ~ clip(round(N(mean_nodes,
+ * std_nodes)), min_nodes, max_nodes); bond type t+1 with probability bond_prob[t] (t < num_bond_types <= 8); atom types
+ * uniform in [0, num_atom_types).  QM9-shaped batches: N(18,3) clipped to [4,29], 4 bond types. */
+typedef struct kpgnn_synth_shape {
+    double mean_nodes, std_nodes;
+    int32_t min_nodes, max_nodes;
+    int32_t num_bond_types;
+    double bond_prob[8];
+    int32_t num_atom_types;
+} kpgnn_synth_shape;
+int kpgnn_synth_molecules_ex(const kpgnn_synth_shape* shape, int64_t G, uint64_t seed0, int64_t* node_ptr,
+                             int64_t* edge_ptr, int64_t* edge_index, int64_t* edge_attr, int64_t* atom_type);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ import torch
 from . import khop_transform as KT
 from .khop_csr import KHopCSR, attach_khop_csr
 
-_TENSORS = ("x", "edge_index", "edge_attr", "pe_attr", "peripheral_edge_attr", "peripheral_configuration_attr",
+_TENSORS = ("x", "z", "edge_index", "edge_attr", "pe_attr", "peripheral_edge_attr", "peripheral_configuration_attr",
             "batch", "y")
 
 
@@ -44,6 +44,8 @@ def collate_khop(node_ptr, edge_ptr, edge_index, edge_attr, x, khop_args, y=None
     xt = torch.as_tensor(x)
     if xt.dim() == 1:
         xt = xt.view(-1, 1)
+    if edge_attr is None:
+        edge_attr = None
     return KHopBatch(x=xt, edge_index=out["edge_index"], edge_attr=out["edge_attr"], pe_attr=out["pe_attr"],
                      peripheral_edge_attr=out["peripheral_edge_attr"],
                      peripheral_configuration_attr=out["peripheral_configuration_attr"], batch=out["batch"], y=y,
@@ -57,3 +59,37 @@ def synthetic_zinc_batch(num_graphs, seed0, K=8, kernel="spd", num_threads=0):
     g = torch.Generator().manual_seed(int(seed0))
     y = torch.randn(num_graphs, generator=g)
     return collate_khop(node_ptr, edge_ptr, ei, ea, x, (K, 50, 6, 3, 50, 50, kernel), y=y, num_threads=num_threads)
+
+
+def synthetic_qm9_batch(num_graphs, seed0, K=6, kernel="spd", num_threads=0):
+    """QM9-shaped synthetic batch with the reference's QM9 pre-transform arguments (train_qm9.py:141-158: max_pe_num=50,
+    max_hop_num=5, max_edge_type=4, max_edge_count=20, max_distance_count=15): 11 node features (PyG QM9's x) + the atomic
+    number z, whose 8-wide embedding makes up the encoder's 19 inputs (layers/input_encoder.py:43-84), one regression target."""
+    node_ptr, edge_ptr, ei, ea, atom = KT.synth_molecules(num_graphs, seed0, shape=KT.qm9_shape())
+    g = torch.Generator().manual_seed(int(seed0))
+    n = int(node_ptr[-1])
+    x = torch.randn(n, 11, generator=g)
+    z = torch.tensor([1, 6, 7, 8, 9])[torch.as_tensor(atom)]          # H, C, N, O, F
+    y = torch.randn(num_graphs, generator=g)
+    b = collate_khop(node_ptr, edge_ptr, ei, ea, x, (K, 50, 5, 4, 20, 15, kernel), y=y, num_threads=num_threads)
+    b.z = z
+    return b
+
+
+def synthetic_regular_batch(num_graphs, seed0, n=1280, degree=3, K=8, num_threads=0):
+    """run_simulation.py's workload (:96-129): `num_graphs` random `degree`-regular graphs on n nodes
+    (nx.random_regular_graph(d, n, seed), seeds seed0, seed0+1, ..), x = ones [n,1], pre-transform arguments
+    (k, 10, 1, 1, 1, 1, "spd") (:103)."""
+    import networkx as nx
+    import numpy as np
+    eis, node_ptr, edge_ptr = [], [0], [0]
+    for s in range(num_graphs):
+        G = nx.random_regular_graph(d=degree, n=n, seed=int(seed0) + s)
+        e = np.array(sorted(G.to_directed().edges), dtype=np.int64).T      # (src, dst) sorted, as from_networkx emits them
+        eis.append(e)
+        node_ptr.append(node_ptr[-1] + n)
+        edge_ptr.append(edge_ptr[-1] + e.shape[1])
+    ei = np.ascontiguousarray(np.concatenate(eis, axis=1))
+    x = torch.ones(num_graphs * n, 1)
+    return collate_khop(np.array(node_ptr, dtype=np.int64), np.array(edge_ptr, dtype=np.int64), ei, None, x,
+                        (K, 10, 1, 1, 1, 1, "spd"), num_threads=num_threads)

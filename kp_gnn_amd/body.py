@@ -103,6 +103,32 @@ class EmbeddingEncoder(nn.Module):
         return self.init_proj(data.x)
 
 
+class QM9InputEncoder(nn.Module):
+    """layers/input_encoder.py:43-84: Linear over cat(Embedding(z), continuous features [, pos])."""
+
+    def __init__(self, hidden_size, use_pos=False):
+        super().__init__()
+        self.use_pos = use_pos
+        self.init_proj = nn.Linear(22 if use_pos else 19, hidden_size)
+        self.z_embedding = nn.Embedding(1000, 8)
+
+    def reset_parameters(self):
+        self.init_proj.reset_parameters()
+        self.z_embedding.reset_parameters()
+
+    def forward(self, data):
+        x, z = data.x, _get(data, "z")
+        if z is not None:
+            z_emb = embedding_rows(self.z_embedding.weight, z) if z.is_cuda else self.z_embedding(z)
+            if z_emb.dim() == 3:
+                z_emb = z_emb.sum(dim=1)
+            x = torch.cat([z_emb, x], -1)
+        pos = _get(data, "pos")
+        if self.use_pos and pos is not None:
+            x = torch.cat([x, pos], 1)
+        return self.init_proj(x)
+
+
 class LinearEncoder(nn.Module):
     """layers/input_encoder.py:26-40."""
 

@@ -421,10 +421,13 @@ struct Molecule {
     std::vector<int> atom;
 };
 
-void make_molecule(uint64_t seed, Molecule* m) {
+// (defaults = the ZINC-12k shape of SURVEY.md Appendix A.2)
+const kpgnn_synth_shape kZincShape = {23.2, 4.5, 9, 37, 3, {0.75, 0.20, 0.05, 0, 0, 0, 0, 0}, 21};
+
+void make_molecule(uint64_t seed, Molecule* m, const kpgnn_synth_shape& sh) {
     SplitMix64 rng(seed);
-    int n = (int)std::lround(23.2 + 4.5 * rng.normal());
-    n = std::max(9, std::min(37, n));
+    int n = (int)std::lround(sh.mean_nodes + sh.std_nodes * rng.normal());
+    n = std::max(sh.min_nodes, std::min(sh.max_nodes, n));
     m->n = n;
     m->undirected.clear(); m->bond.clear(); m->atom.clear();
     std::vector<int> deg(n, 0);
@@ -473,16 +476,28 @@ void make_molecule(uint64_t seed, Molecule* m) {
     }
     for (size_t e = 0; e < m->undirected.size(); ++e) {
         const double u = rng.uniform();
-        m->bond.push_back(u < 0.75 ? 1 : (u < 0.95 ? 2 : 3));
+        double acc = 0;
+        int b = sh.num_bond_types;
+        for (int t = 0; t < sh.num_bond_types; ++t) { acc += sh.bond_prob[t]; if (u < acc) { b = t + 1; break; } }
+        m->bond.push_back(b);
     }
-    for (int v = 0; v < n; ++v) m->atom.push_back((int)rng.below(21));
+    for (int v = 0; v < n; ++v) m->atom.push_back((int)rng.below(sh.num_atom_types));
 }
 
 }  // namespace
 
 extern "C" int kpgnn_synth_molecules(int64_t G, uint64_t seed0, int64_t* node_ptr, int64_t* edge_ptr,
                                      int64_t* edge_index, int64_t* edge_attr, int64_t* atom_type) {
+    return kpgnn_synth_molecules_ex(nullptr, G, seed0, node_ptr, edge_ptr, edge_index, edge_attr, atom_type);
+}
+
+extern "C" int kpgnn_synth_molecules_ex(const kpgnn_synth_shape* shape, int64_t G, uint64_t seed0, int64_t* node_ptr,
+                                        int64_t* edge_ptr, int64_t* edge_index, int64_t* edge_attr, int64_t* atom_type) {
     if (G < 0 || !node_ptr || !edge_ptr) return fail(KPGNN_HOST_EINVAL, "synth_molecules: NULL node_ptr/edge_ptr");
+    const kpgnn_synth_shape sh = shape ? *shape : kZincShape;
+    if (sh.min_nodes < 1 || sh.max_nodes < sh.min_nodes || sh.num_bond_types < 1 || sh.num_bond_types > 8 || sh.num_atom_types < 1)
+        return fail(KPGNN_HOST_EINVAL, "synth_molecules: bad shape (nodes %d..%d, %d bond types, %d atom types)", sh.min_nodes,
+                    sh.max_nodes, sh.num_bond_types, sh.num_atom_types);
     const bool fill = edge_index != nullptr;
     if (!fill) {
         node_ptr[0] = 0; edge_ptr[0] = 0;
@@ -490,7 +505,7 @@ extern "C" int kpgnn_synth_molecules(int64_t G, uint64_t seed0, int64_t* node_pt
 #pragma omp parallel for schedule(static, 64)
         for (int64_t gi = 0; gi < G; ++gi) {
             Molecule m;
-            make_molecule(seed0 + (uint64_t)gi, &m);
+            make_molecule(seed0 + (uint64_t)gi, &m, sh);
             nn[(size_t)gi] = m.n;
             ne[(size_t)gi] = 2 * (int64_t)m.undirected.size();
         }
@@ -505,7 +520,7 @@ extern "C" int kpgnn_synth_molecules(int64_t G, uint64_t seed0, int64_t* node_pt
 #pragma omp parallel for schedule(static, 64)
     for (int64_t gi = 0; gi < G; ++gi) {
         Molecule m;
-        make_molecule(seed0 + (uint64_t)gi, &m);
+        make_molecule(seed0 + (uint64_t)gi, &m, sh);
         if (node_ptr[gi + 1] - node_ptr[gi] != m.n || edge_ptr[gi + 1] - edge_ptr[gi] != 2 * (int64_t)m.undirected.size()) {
             bad = 1;
             continue;

@@ -33,6 +33,7 @@ HOST_SIGNATURES = {
     "kpgnn_khop_plan_export": (ctypes.c_int, [ctypes.c_void_p] + [c_i64p] * 6),
     "kpgnn_khop_plan_destroy": (None, [ctypes.c_void_p]),
     "kpgnn_synth_molecules": (ctypes.c_int, [ctypes.c_int64, ctypes.c_uint64] + [c_i64p] * 5),
+    "kpgnn_synth_molecules_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64] + [c_i64p] * 5),
 }
 
 _host = None
@@ -137,17 +138,34 @@ def extract_multi_hop_neighbors(data, K, max_edge_attr_num, max_hop_num, max_edg
     return data
 
 
-def synth_molecules(num_graphs, seed0=0):
-    """ZINC-12k-shaped synthetic molecule graphs (see kpgnn_host.h).  Returns numpy int64 arrays
-    node_ptr [G+1], edge_ptr [G+1], edge_index [2,E] (local ids), edge_attr [E] (types 2..4), x [N]."""
+class SynthShape(ctypes.Structure):
+    """kpgnn_synth_shape (include/kpgnn_host.h)."""
+    _fields_ = [("mean_nodes", ctypes.c_double), ("std_nodes", ctypes.c_double), ("min_nodes", ctypes.c_int32),
+                ("max_nodes", ctypes.c_int32), ("num_bond_types", ctypes.c_int32), ("bond_prob", ctypes.c_double * 8),
+                ("num_atom_types", ctypes.c_int32)]
+
+
+def qm9_shape():
+    """QM9-shaped molecules: n ~ N(18, 3) clipped to [4, 29], 4 bond types."""
+    sh = SynthShape()
+    sh.mean_nodes, sh.std_nodes, sh.min_nodes, sh.max_nodes, sh.num_bond_types, sh.num_atom_types = 18.0, 3.0, 4, 29, 4, 5
+    for i, v in enumerate((0.70, 0.20, 0.07, 0.03)):
+        sh.bond_prob[i] = v
+    return sh
+
+
+def synth_molecules(num_graphs, seed0=0, shape=None):
+    """Synthetic molecule graphs (see kpgnn_host.h; shape None = ZINC-12k-shaped).  Returns numpy int64 arrays
+    node_ptr [G+1], edge_ptr [G+1], edge_index [2,E] (local ids), edge_attr [E] (types 2..), x [N]."""
     lib = load_host()
     G = int(num_graphs)
+    sp = ctypes.byref(shape) if shape is not None else None
     node_ptr = np.zeros(G + 1, dtype=np.int64)
     edge_ptr = np.zeros(G + 1, dtype=np.int64)
-    _check(lib.kpgnn_synth_molecules(G, seed0, _p(node_ptr), _p(edge_ptr), None, None, None), "kpgnn_synth_molecules")
+    _check(lib.kpgnn_synth_molecules_ex(sp, G, seed0, _p(node_ptr), _p(edge_ptr), None, None, None), "kpgnn_synth_molecules_ex")
     ei = np.empty((2, int(edge_ptr[-1])), dtype=np.int64)
     ea = np.empty(int(edge_ptr[-1]), dtype=np.int64)
     x = np.empty(int(node_ptr[-1]), dtype=np.int64)
-    _check(lib.kpgnn_synth_molecules(G, seed0, _p(node_ptr), _p(edge_ptr), _p(ei), _p(ea), _p(x)),
-           "kpgnn_synth_molecules")
+    _check(lib.kpgnn_synth_molecules_ex(sp, G, seed0, _p(node_ptr), _p(edge_ptr), _p(ei), _p(ea), _p(x)),
+           "kpgnn_synth_molecules_ex")
     return node_ptr, edge_ptr, ei, ea, x

@@ -52,6 +52,6 @@ class KGINConv(KHopMessagePassing):
         h = F.relu(torch.baddbmm(self.hop_bias2.unsqueeze(1), h, self.hop_proj2))
         out = self.combine_proj(h.transpose(0, 1).reshape(n, self.K * self.hidden_size))
         if self.pool:
-            size = int(batch[-1].item()) + 1
-            out = out.new_zeros(size, out.size(1)).index_add_(0, batch, out)
+            from ..ops import segment_pool
+            out = segment_pool(out, batch, int(batch[-1].item()) + 1)     # global_add_pool (run_simulation.py:83-84)
         return out

@@ -223,8 +223,8 @@ def gine_forward(p, x, edge_index, edge_attr, *, training=True):
     return mlp_bn(p, "mlp", out.squeeze(), training)
 
 
-def kgin_forward(p, x, edge_index, edge_attr, *, K):
-    """run_simulation.py:70-85 without the optional pooling: mask-only K-hop GIN."""
+def kgin_forward(p, x, edge_index, edge_attr, *, K, batch=None):
+    """run_simulation.py:70-85: mask-only K-hop GIN; `batch` given = the script's `args.graph` sum pooling (:83-84)."""
     hs = p["hop_proj1"].shape[1]
     x = F.linear(x, p["proj.weight"], p["proj.bias"]).view(-1, K, hs)
     x_j = x.index_select(0, edge_index[0])
@@ -234,4 +234,7 @@ def kgin_forward(p, x, edge_index, edge_attr, *, K):
     x = F.relu(torch.matmul(x, p["hop_proj1"]) + p["hop_bias1"].unsqueeze(1))
     x = F.relu(torch.matmul(x, p["hop_proj2"]) + p["hop_bias2"].unsqueeze(1))
     x = x.permute(1, 0, 2).contiguous().view(-1, K * hs)
-    return F.linear(x, p["combine_proj.weight"], p["combine_proj.bias"])
+    x = F.linear(x, p["combine_proj.weight"], p["combine_proj.bias"])
+    if batch is not None:
+        x = x.new_zeros(int(batch[-1]) + 1, x.size(1)).index_add_(0, batch, x)
+    return x

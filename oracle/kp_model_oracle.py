@@ -48,7 +48,13 @@ def body_forward(p, data, *, kind, layer_kind, K, num_layer, combine_kind, JK="c
     peripheral_configuration_attr.  layer_kind in {KPGIN, KPGCN, KPGINPlus}.  Dropout prob 0 assumed."""
     edge_index, edge_attr, batch = data["edge_index"], data["edge_attr"], data["batch"]
     pe_attr = data.get("pe_attr")
-    x = F.embedding(data["x"], p["init_proj.init_proj.weight"]).squeeze()
+    if "init_proj.z_embedding.weight" in p:      # QM9InputEncoder (layers/input_encoder.py:63-84)
+        xin = data["x"]
+        if data.get("z") is not None:
+            xin = torch.cat([F.embedding(data["z"], p["init_proj.z_embedding.weight"]), xin], -1)
+        x = F.linear(xin, p["init_proj.init_proj.weight"], p["init_proj.init_proj.bias"])
+    else:
+        x = F.embedding(data["x"], p["init_proj.init_proj.weight"]).squeeze()
     N = x.size(0)
     H = x.size(1)
     gate = torch.tanh if kind == "GNNPlus" else torch.sigmoid

@@ -430,8 +430,59 @@ def make_body_goldens(outdir):
     print(f"bodies.pt: {len(cases)} cases")
 
 
+# ----------------------------------------------------------------------------- run_simulation.py's KGINConv
+def reference_kgin_class(graph_pool):
+    """The reference's `KGINConv` (run_simulation.py:29-93) WITHOUT running the script: run_simulation.py has no
+    `__main__` guard around its experiment, so importing it would run the whole simulation.  The class definition is cut
+    out of the parsed source (ast) and executed alone, in a namespace that holds what the script's imports would have
+    given it (torch, nn, F, math, the stand-in MessagePassing / global_add_pool) and the module-global `args.graph` the
+    class reads (:83).  Nothing of the source text is stored."""
+    import ast
+    import math
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch_geometric.nn import MessagePassing, global_add_pool
+    path = os.path.join(REF, "run_simulation.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "KGINConv"]
+    assert len(node) == 1
+    ns = {"torch": torch, "nn": nn, "F": F, "math": math, "MessagePassing": MessagePassing,
+          "global_add_pool": global_add_pool, "args": argparse.Namespace(graph=graph_pool)}
+    exec(compile(ast.Module(body=node, type_ignores=[]), path, "exec"), ns)
+    return ns["KGINConv"]
+
+
+def make_kgin_goldens(outdir):
+    graphs = input_graphs()
+    cases = {}
+    for name, gnames, pre, K, hs, pool, seed in (("kgin_reg40_k4", ["reg3_n40_s1"], "sim_k4_spd", 4, 16, False, 1),
+                                                 ("kgin_reg64_k8", ["reg3_n64_s2"], "sim_k8_spd", 8, 16, False, 2),
+                                                 ("kgin_2graphs_k4_pool", ["reg3_n20_s0", "reg3_n40_s1"], "sim_k4_spd", 4, 8, True, 3)):
+        datas = []
+        for gn in gnames:
+            x, ei, ea = graphs[gn]
+            r = run_pretransform(x, ei, ea, PRE_ARGS[pre])
+            datas.append(Data(x=x.clone(), edge_index=r["edge_index"], edge_attr=r["edge_attr"]))
+        b = Batch.from_data_list(datas)
+        torch.manual_seed(seed)
+        layer = reference_kgin_class(pool)(hs, K)
+        sd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+        gen = torch.Generator().manual_seed(seed)
+        x = (b.x + 0.1 * torch.randn(b.x.shape, generator=gen)).requires_grad_(True)
+        out = layer(x, b.edge_index, b.edge_attr, b.batch)
+        w = torch.randn(out.shape, generator=gen)
+        (out * w).sum().backward()
+        cases[name] = {"K": K, "hidden_size": hs, "pool": pool, "state_dict": sd, "x": x.detach().clone(),
+                       "edge_index": b.edge_index.clone(), "edge_attr": b.edge_attr.clone(), "batch": b.batch.clone(),
+                       "out": out.detach().clone(), "out_weight": w, "grad_x": x.grad.clone(), "param_grads": grads_of(layer)}
+    torch.save(cases, os.path.join(outdir, "kgin.pt"))
+    print(f"kgin.pt: {len(cases)} cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pre", "layers", "combine", "bodies"]
+    which = sys.argv[1:] or ["pre", "layers", "combine", "bodies", "kgin"]
+    if "kgin" in which:
+        make_kgin_goldens(HERE)
     if "pre" in which:
         make_preprocess_goldens(HERE)
     if "combine" in which:

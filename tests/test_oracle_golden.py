@@ -152,3 +152,19 @@ def test_body_oracle_matches_reference(golden_dir):
             got = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
             assert torch.allclose(got, g, rtol=1e-3, atol=2e-5 * max(1.0, gscale)), \
                 (name, k, float((got - g).abs().max()), gscale)
+
+
+def test_kgin_oracle_matches_reference_goldens(golden_dir):
+    """oracle.kgin_forward (run_simulation.py's mask-only KGINConv) against vectors produced by the reference's own class
+    (cut out of run_simulation.py with ast and executed alone, tests/golden/make_golden.py): output and every gradient."""
+    cases = torch.load(os.path.join(golden_dir, "kgin.pt"), weights_only=True)
+    assert len(cases) >= 3
+    for name, c in cases.items():
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "eps") for k, v in c["state_dict"].items()}
+        x = c["x"].clone().requires_grad_(True)
+        out = LO.kgin_forward(p, x, c["edge_index"], c["edge_attr"], K=c["K"], batch=c["batch"] if c["pool"] else None)
+        (out * c["out_weight"]).sum().backward()
+        _close(out, c["out"], name + ":out")
+        _close(x.grad, c["grad_x"], name + ":grad_x")
+        for k, g in c["param_grads"].items():
+            _close(p[k].grad, g, f"{name}:grad[{k}]")
