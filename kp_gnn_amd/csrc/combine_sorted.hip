@@ -73,35 +73,17 @@ combine_sorted_kernel(const CsParams p) {
     const int cc = col_ok ? c0 : 0;                   // idle lanes re-read column 0 and are dropped at the stores
 
     const int64_t total_sg = (int64_t)gridDim.x * NODES;
-    // The segment header (3 words) and the segment's first G entries of the NEXT segment this sub-group will walk are requested
-    // while the current one is processed: two of the three dependent round trips per segment (header -> entries -> rows)
-    // leave the critical path.
-    int64_t seg = (int64_t)blockIdx.x * NODES + sg;
-    int nbeg = 0, nend = 0; uint32_t nkey = 0, n_node = 0, n_mw = 0;
-    if (seg < p.nseg) {
-        nbeg = p.seg_ptr[seg]; nend = p.seg_ptr[seg + 1]; nkey = p.seg_key[seg];
-        if (nbeg + sl < nend) { n_node = p.ent[2 * (int64_t)(nbeg + sl)]; n_mw = p.ent[2 * (int64_t)(nbeg + sl) + 1]; }
-    }
-    for (; seg < p.nseg; seg += total_sg) {
-        const int beg = nbeg, end = nend;
-        const uint32_t key = nkey;
-        uint32_t first_node = n_node, first_mw = n_mw;
-        if (seg + total_sg < p.nseg) {
-            nbeg = p.seg_ptr[seg + total_sg]; nend = p.seg_ptr[seg + total_sg + 1]; nkey = p.seg_key[seg + total_sg];
-            n_node = 0; n_mw = 0;
-            if (nbeg + sl < nend) { n_node = p.ent[2 * (int64_t)(nbeg + sl)]; n_mw = p.ent[2 * (int64_t)(nbeg + sl) + 1]; }
-        }
+    for (int64_t seg = (int64_t)blockIdx.x * NODES + sg; seg < p.nseg; seg += total_sg) {
+        const int beg = p.seg_ptr[seg], end = p.seg_ptr[seg + 1];
+        const uint32_t key = p.seg_key[seg];
         const int k = (int)(key >> 16);
         float thv[VEC], acc[VEC], gt[VEC];
         for (int q = 0; q < VEC; ++q) { thv[q] = 0.f; acc[q] = 0.f; gt[q] = 0.f; }
         if (fused) ldv<VEC>(thp + k * D + cc, thv);
         for (int base = beg; base < end; base += G) {
             // lane sl holds entry base + sl of the segment (one coalesced load), broadcast below
-            uint32_t my_node = first_node, my_mw = first_mw;
-            if (base != beg) {
-                my_node = 0; my_mw = 0;
-                if (base + sl < end) { my_node = p.ent[2 * (int64_t)(base + sl)]; my_mw = p.ent[2 * (int64_t)(base + sl) + 1]; }
-            }
+            uint32_t my_node = 0, my_mw = 0;
+            if (base + sl < end) { my_node = p.ent[2 * (int64_t)(base + sl)]; my_mw = p.ent[2 * (int64_t)(base + sl) + 1]; }
             const int cnt = min(G, end - base);
             for (int t0 = 0; t0 < cnt; t0 += UN) {
                 float s[UN][VEC], gvv[UN][VEC], ghv[UN][VEC], pv[UN][VEC];
@@ -187,33 +169,21 @@ dict_grad_kernel(const DgParams p, int CW) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) th[j] = grp + kDgGroups * j < p.K ? p.theta[(grp + kDgGroups * j) * p.D + col] : 0.f;
         float* acc = lds + (int64_t)grp * p.U * CW + col;
-        // four nodes per trip; the next trip's operands are requested before this trip's LDS updates (whose read-modify-write
-        // chain the compiler must keep in order), so the global round trip is hidden behind them
-        float gv[4], ngv[4]; int uu[4][4], nuu[4][4];
-        auto fetch = [&](int64_t m, float (&g)[4], int (&u)[4][4]) {
+        for (int64_t m = m0; m < m1; m += 4) {        // four nodes per trip: their loads do not wait for the LDS updates
+            float gv[4]; int uu[4][4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const bool ok = m + n < m1;
-                g[n] = ok ? p.gh[(m + n) * p.D + col] : 0.f;
+                gv[n] = ok ? p.gh[(m + n) * p.D + col] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    u[n][j] = (ok && grp + kDgGroups * j < p.K) ? p.uid[(m + n) * p.uid_stride + grp + kDgGroups * j] : -1;
+                    uu[n][j] = (ok && grp + kDgGroups * j < p.K) ? p.uid[(m + n) * p.uid_stride + grp + kDgGroups * j] : -1;
             }
-        };
-        fetch(m0, gv, uu);
-        for (int64_t m = m0; m < m1; m += 4) {
-            fetch(m + 4, ngv, nuu);
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (uu[n][j] >= 0) acc[uu[n][j] * CW] = fmaf(th[j], gv[n], acc[uu[n][j] * CW]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                gv[n] = ngv[n];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) uu[n][j] = nuu[n][j];
-            }
         }
     }
     __syncthreads();
@@ -237,88 +207,82 @@ struct FinParams {
     const float* alpha; const float* theta; float* galpha;
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 combine_finish_kernel(const FinParams p) {
-    __shared__ float part[16][16][17];               // [output k][slice][column]
-    const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;     // 16 slices x 16 columns
+    __shared__ float part[64][17];
+    int range[2];
+    const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int col = blockIdx.y * 16 + o;
     const bool col_ok = col < p.D;
     const int r = blockIdx.x;
-    // sum of slab rows [a, b) strided over the slices (independent loads, four per trip)
-    auto slice_sum = [&](const float* slab, int a, int b) -> float {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (!col_ok) return 0.f;
-        int i = a + slice;
-        for (; i + 48 < b; i += 64) {
-            s0 += slab[(int64_t)i * p.D + col]; s1 += slab[(int64_t)(i + 16) * p.D + col];
-            s2 += slab[(int64_t)(i + 32) * p.D + col]; s3 += slab[(int64_t)(i + 48) * p.D + col];
-        }
-        for (; i < b; i += 16) s0 += slab[(int64_t)i * p.D + col];
-        return (s0 + s1) + (s2 + s3);
-    };
-    auto combine = [&](int nout) {                   // part[k][slice][o] -> total of output k in slice 0 (returned per k via part[k][0][o])
-        __syncthreads();
-        if (slice == 0)
-            for (int k = 0; k < nout; ++k) {
-                float tot = 0.f;
-                for (int q = 0; q < 16; ++q) tot += part[k][q][o];
-                part[k][0][o] = tot;
-            }
-    };
-    const int NC1 = p.NC + 1;
-    if (r < p.n0 + p.nk) {
-        if (!p.want_tab) return;
-        // segments of (hop h, code c): [key_ptr[h*(NC+1)+c], key_ptr[h*(NC+1)+c+1]) clipped to the first nseg segments; codes
-        // the CSR never holds (c >= NC) have none.  gtablek sums the hops 1..K-1: all ranges are fetched up front
-        const bool t0 = r < p.n0;
-        const int code = t0 ? r : r - p.n0;
-        int a[16], b[16];
-#pragma unroll
-        for (int h = 0; h < 16; ++h) {
-            const bool use = code < p.NC && (t0 ? h == 0 : (h >= 1 && h < p.K));
-            a[h] = use ? min(p.key_ptr[h * NC1 + code], p.nseg) : 0;
-            b[h] = use ? min(p.key_ptr[h * NC1 + code + 1], p.nseg) : 0;
-        }
+    auto block_sum = [&](const float* slab, int a, int b) -> float {      // sum of slab rows [a, b), valid in slice 0
         float s = 0.f;
-#pragma unroll
-        for (int h = 0; h < 16; ++h) if (b[h] > a[h]) s += slice_sum(p.slab_tab, a[h], b[h]);
-        part[0][slice][o] = s;
-        combine(1);
-        if (slice == 0 && col_ok) (t0 ? p.gtable0 : p.gtablek)[(int64_t)code * p.D + col] = part[0][0][o];
+        if (col_ok) for (int i = a + slice; i < b; i += 64) s += slab[(int64_t)i * p.D + col];
+        __syncthreads();
+        part[slice][o] = s;
+        __syncthreads();
+        float tot = 0.f;
+        if (slice == 0) for (int q = 0; q < 64; ++q) tot += part[q][o];
+        return tot;
+    };
+    // segments of (hop h, code c): [key_ptr[h*(NC+1)+c], key_ptr[h*(NC+1)+c+1]) clipped to the first nseg segments; codes the
+    // CSR never holds (c >= NC) have none
+    auto key_range = [&](int h, int c) {
+        range[0] = range[1] = 0;
+        if (c < p.NC) {
+            range[0] = min(p.key_ptr[h * (p.NC + 1) + c], p.nseg);
+            range[1] = min(p.key_ptr[h * (p.NC + 1) + c + 1], p.nseg);
+        }
+    };
+    if (r < p.n0) {
+        if (!p.want_tab) return;
+        key_range(0, r);
+        const float tot = block_sum(p.slab_tab, range[0], range[1]);
+        if (slice == 0 && col_ok) p.gtable0[(int64_t)r * p.D + col] = tot;
+    } else if (r < p.n0 + p.nk) {
+        if (!p.want_tab) return;
+        const int code = r - p.n0;
+        float tot = 0.f;
+        for (int h = 1; h < p.K; ++h) {
+            key_range(h, code);
+            tot += block_sum(p.slab_tab, range[0], range[1]);
+        }
+        if (slice == 0 && col_ok) p.gtablek[(int64_t)code * p.D + col] = tot;
     } else if (r == p.n0 + p.nk) {
         if (!p.want_th) return;
-        for (int k = 0; k < p.K; ++k) part[k][slice][o] = slice_sum(p.slab_th, p.hop_seg[k], min(p.hop_seg[k + 1], p.nseg));
-        combine(p.K);
-        if (slice == 0 && col_ok) {
-            float gth[16];
+        float gth[16];
+        for (int k = 0; k < p.K; ++k) {
+            const int a = p.hop_seg[k], b = min(p.hop_seg[k + 1], p.nseg);
+            gth[k] = block_sum(p.slab_th, a, b);
+            if (slice == 0 && col_ok && p.gtheta) p.gtheta[(int64_t)k * p.D + col] = gth[k];
+        }
+        if (p.galpha && slice == 0 && col_ok) {
+            // dt[k] = theta[k] (G[k] - sum_j theta[j] G[j]);  dt[k]/da = q^k - k a q^(k-1);  da/dalpha = a q  (geo_theta.hip)
+            const float a = 1.0f / (1.0f + __expf(-p.alpha[col]));
+            const float q = 1.0f - a;
+            float dot = 0.f;
+            for (int k = 0; k < p.K; ++k) dot = fmaf(p.theta[(int64_t)k * p.D + col], gth[k], dot);
+            float acc = 0.f, pw = 1.0f, pwm1 = 0.f;
             for (int k = 0; k < p.K; ++k) {
-                gth[k] = part[k][0][o];
-                if (p.gtheta) p.gtheta[(int64_t)k * p.D + col] = gth[k];
+                const float dt = p.theta[(int64_t)k * p.D + col] * (gth[k] - dot);
+                acc = fmaf(dt, pw - (float)k * a * pwm1, acc);
+                pwm1 = pw;
+                pw *= q;
             }
-            if (p.galpha) {
-                // dt[k] = theta[k] (G[k] - sum_j theta[j] G[j]);  dt[k]/da = q^k - k a q^(k-1);  da/dalpha = a q  (geo_theta.hip)
-                const float a = 1.0f / (1.0f + __expf(-p.alpha[col]));
-                const float q = 1.0f - a;
-                float dot = 0.f;
-                for (int k = 0; k < p.K; ++k) dot = fmaf(p.theta[(int64_t)k * p.D + col], gth[k], dot);
-                float acc = 0.f, pw = 1.0f, pwm1 = 0.f;
-                for (int k = 0; k < p.K; ++k) {
-                    const float dt = p.theta[(int64_t)k * p.D + col] * (gth[k] - dot);
-                    acc = fmaf(dt, pw - (float)k * a * pwm1, acc);
-                    pwm1 = pw;
-                    pw *= q;
-                }
-                p.galpha[col] = a * q * acc;
-            }
+            p.galpha[col] = a * q * acc;
         }
     } else {
         const int u = r - (p.n0 + p.nk + 1);
         if (u >= p.U) return;
         float s = 0.f;
-        if (col_ok) for (int b = slice; b < p.ndict_blocks; b += 16) s += p.slab_dict[((int64_t)b * p.U + u) * p.D + col];
-        part[0][slice][o] = s;
-        combine(1);
-        if (slice == 0 && col_ok) p.gdict[(int64_t)u * p.D + col] = part[0][0][o];
+        if (col_ok) for (int b = slice; b < p.ndict_blocks; b += 64) s += p.slab_dict[((int64_t)b * p.U + u) * p.D + col];
+        part[slice][o] = s;
+        __syncthreads();
+        if (slice == 0 && col_ok) {
+            float tot = 0.f;
+            for (int q = 0; q < 64; ++q) tot += part[q][o];
+            p.gdict[(int64_t)u * p.D + col] = tot;
+        }
     }
 }
 
@@ -373,8 +337,8 @@ bool dict_plan(int N, int D, int U, DictPlan* pl) {
     while (cw < D) cw <<= 1;
     const size_t lds = sizeof(float) * (size_t)kDgGroups * U * cw;
     if (lds > 128 * 1024) return false;
-    int64_t blocks = ((int64_t)N + 31) / 32;                      // >= 32 nodes per block
-    const int64_t cap = (int64_t)device_facts().cu_count * 3;
+    int64_t blocks = ((int64_t)N + 63) / 64;                      // >= 64 nodes per block
+    const int64_t cap = (int64_t)device_facts().cu_count * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     pl->CW = cw; pl->blocks = (int)blocks; pl->lds = lds;
@@ -460,7 +424,7 @@ extern "C" int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_st
     f.gtable0 = d->gtable0; f.gtablek = d->gtablek; f.gtheta = d->gtheta; f.gdict = d->gdict;
     f.alpha = d->alpha; f.theta = d->theta; f.galpha = d->galpha;
     const unsigned rows = (unsigned)(f.n0 + f.nk + 1 + f.U);
-    hipLaunchKernelGGL(combine_finish_kernel, dim3(rows, (unsigned)((d->D + 15) / 16)), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(combine_finish_kernel, dim3(rows, (unsigned)((d->D + 15) / 16)), dim3(1024), 0, s, f);
     KPGNN_LAUNCH_CHECK("combine_finish_kernel");
     return KPGNN_OK;
 }
