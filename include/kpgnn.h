@@ -91,14 +91,11 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
  *   seg_key  uint32[<= A + N*K]: hop << 16 | code of the segment (ascending)
  *   hop_seg  int32[K + 1]: number of segments of hops < k
  *   counts   int32[2]: NE (entries), NS (segments) - device memory; read them back once to size the consumers' slabs
- *   key_ptr  optional int32[K * (num_codes + 1)]: key_ptr[h*(num_codes+1) + c] = first segment with key >= (hop h, code c),
- *            so the segments of (h, c) are [key_ptr[.. + c], key_ptr[.. + c + 1]) for c < num_codes (num_codes > every real code)
  * K <= 62, codes <= 65534.  Integer work only: bitwise reproducible. */
 size_t kpgnn_csr_code_segments_workspace_bytes(int64_t N, int32_t K, int64_t A);
 int kpgnn_csr_code_segments(const int32_t* rowptr_dst, const uint16_t* code_dst, int64_t N, int32_t K, int64_t A,
                             uint32_t* entries, int32_t* seg_ptr, uint32_t* seg_key, int32_t* hop_seg, int32_t* counts,
-                            int32_t num_codes, int32_t* key_ptr, void* workspace, size_t workspace_bytes,
-                            kpgnn_stream_t stream);
+                            void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
@@ -159,10 +156,6 @@ typedef struct kpgnn_agg_fwd_desc {
     /* Geometric combine computed by the launch itself: alphas [D] (device) - theta[k,d] = softmax_k(a (1-a)^k) with
      * a = sigmoid(alphas[d]) (combine.py:43-50) is then an OUTPUT, written to `theta` ([K,D]) for the backward. */
     const float* alphas;
-    /* Layout of `pre` (S saved for the backward): row (i,k) at pre + i*pre_sn + k*pre_sk.  0 / 0 = contiguous [N,K,D].
-     * kpgnn_combine_sorted walks the rows hop by hop: for it the forward stores S hop-major ([K,N,D]: pre_sn = D,
-     * pre_sk = N*D), so that rows processed close in time share cache lines. */
-    int64_t pre_sn, pre_sk;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
@@ -280,9 +273,7 @@ typedef struct kpgnn_combine_sorted_desc {
     const float* periph; int64_t p_sn, p_sk;
     const float* ptab; const int32_t* uid; int64_t uid_stride; int32_t n_dict;
     float* g; float* gv;
-    int64_t pre_sn, pre_sk, g_sn, g_sk;   /* row (i,k) of pre / g at i*sn + k*sk; all 0 = contiguous [N,K,D] (gv always is) */
     const uint32_t* entries; const int32_t* seg_ptr; const uint32_t* seg_key; const int32_t* hop_seg;
-    const int32_t* key_ptr; int32_t num_codes;   /* kpgnn_csr_code_segments' key table (required when gtable0 is wanted) */
     int32_t num_segments;
     int32_t n_code0, n_codek;
     float* gtable0; float* gtablek; float* gtheta;

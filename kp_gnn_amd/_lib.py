@@ -27,7 +27,7 @@ class AggFwdDesc(ctypes.Structure):
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
-        ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp), ("pre_sn", c_i64), ("pre_sk", c_i64),
+        ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp),
     ]
 
 
@@ -155,9 +155,8 @@ class CombineSortedDesc(ctypes.Structure):
         ("gout", c_vp), ("go_sn", c_i64), ("go_sk", c_i64),
         ("periph", c_vp), ("p_sn", c_i64), ("p_sk", c_i64),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64), ("n_dict", c_i32),
-        ("g", c_vp), ("gv", c_vp), ("pre_sn", c_i64), ("pre_sk", c_i64), ("g_sn", c_i64), ("g_sk", c_i64),
+        ("g", c_vp), ("gv", c_vp),
         ("entries", c_vp), ("seg_ptr", c_vp), ("seg_key", c_vp), ("hop_seg", c_vp),
-        ("key_ptr", c_vp), ("num_codes", c_i32),
         ("num_segments", c_i32), ("n_code0", c_i32), ("n_codek", c_i32),
         ("gtable0", c_vp), ("gtablek", c_vp), ("gtheta", c_vp),
         ("alpha", c_vp), ("galpha", c_vp), ("gdict", c_vp),
@@ -196,8 +195,8 @@ SIGNATURES = {
     "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
     "kpgnn_csr_code_segments_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i64]),
-    "kpgnn_csr_code_segments": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                               c_vp, ctypes.c_size_t, c_vp]),
+    "kpgnn_csr_code_segments": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               ctypes.c_size_t, c_vp]),
     "kpgnn_combine_sorted_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
     "kpgnn_combine_sorted": (ctypes.c_int, [ctypes.POINTER(CombineSortedDesc), c_vp]),
     "kpgnn_segment_pool_fwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),

@@ -71,7 +71,7 @@ struct FwdParams {
     const float* periph; int64_t p_sn, p_sk;
     const float* eps;
     float* out; int64_t o_sn, o_sk;
-    float* pre; int64_t pre_sn, pre_sk;
+    float* pre;
     const float* theta;
     const float* alphas;        // geometric combine computed in-kernel (theta is then this launch's OUTPUT via theta_out)
     float* theta_out;
@@ -325,7 +325,7 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if (FAST || p.pre) v.store_stream(p.pre + i * p.pre_sn + (int64_t)k * p.pre_sk + c0);
+            if (FAST || p.pre) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
             if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
@@ -702,7 +702,6 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.table0 = d->table0; p.tablek = d->tablek;
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
-    p.pre_sn = d->pre_sn ? d->pre_sn : (int64_t)d->K * d->D; p.pre_sk = d->pre_sn ? d->pre_sk : d->D;   // default: contiguous [N,K,D]
     p.alphas = nullptr; p.theta_out = nullptr;
     if (d->alphas) {
         if (p.lds_theta) { p.alphas = d->alphas; p.theta_out = const_cast<float*>(d->theta); }   // theta staged in LDS: computed there
@@ -723,7 +722,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         return fail(KPGNN_ELIMIT, "aggregate_fwd: N * x row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->x_sn);
     const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
                              {d->x_sn, d->x ? d->x_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
-                              d->out ? d->o_sn : 0, d->out ? d->o_sk : 0, d->pre ? d->pre_sn : 0, d->pre ? d->pre_sk : 0});
+                              d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "aggregate_fwd: D=%d with %d-wide access needs %d lanes > 64", d->D, vec, lanes);
     const int g = pick_group(lanes);

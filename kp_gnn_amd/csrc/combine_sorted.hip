@@ -42,7 +42,6 @@ struct CsParams {
     const float* periph; int64_t p_sn, p_sk;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     float* g; float* gv;
-    int64_t pre_sn, pre_sk, g_sn, g_sk;
     const uint32_t* ent; const int32_t* seg_ptr; const uint32_t* seg_key; int nseg;
     float* slab_tab;     // [nseg][D] or NULL (no table gradients wanted)
     float* slab_th;      // [nseg][D] or NULL
@@ -96,7 +95,7 @@ combine_sorted_kernel(const CsParams p) {
                     if (t0 + u >= cnt) mw[u] = 0u;
                     u_id[u] = -1;
                     for (int q = 0; q < VEC; ++q) pv[u][q] = 0.f;
-                    ldv<VEC>(p.pre + node[u] * p.pre_sn + (int64_t)k * p.pre_sk + cc, s[u]);
+                    ldv<VEC>(p.pre + (node[u] * K + k) * D + cc, s[u]);
                     if (fused) ldv<VEC>(p.gh + node[u] * D + cc, ghv[u]);
                     else ldv<VEC>(p.gout + node[u] * p.go_sn + (int64_t)k * p.go_sk + cc, gvv[u]);
                     if (WGT && (mw[u] >> 31)) {
@@ -129,7 +128,7 @@ combine_sorted_kernel(const CsParams p) {
                         acc[q] = fmaf(mult, gg[q], acc[q]);
                     }
                     if (first && col_ok) {
-                        stv<VEC>(p.g + node[u] * p.g_sn + (int64_t)k * p.g_sk + c0, gg);
+                        stv<VEC>(p.g + (node[u] * K + k) * D + c0, gg);
                         if (p.gv) stv<VEC>(p.gv + (node[u] * K + k) * D + c0, gvv[u]);
                     }
                     if (WGT && first) {
@@ -148,49 +147,45 @@ combine_sorted_kernel(const CsParams p) {
 
 // ---------------------------------------------------------------------------------------------- dictionary gradient
 // slab[b][u][:] = sum over the nodes of block b and hops k with uid[i,k] == u of theta[k,:] * gh[i,:].
-// Block = kDgGroups groups of CW threads (thread = column).  Group q owns the hops k = q, q + kDgGroups, ... of ALL the
-// block's nodes and adds theta[k]*gh[i] into a private [U][CW] table in LDS (plain read-modify-write: no races, fixed
-// order); the dependent LDS chain per node is K / kDgGroups long instead of K.  Groups are then added in order.
-constexpr int kDgGroups = 4;
+// Block = NG groups of CW threads (thread = column); a group walks ITS contiguous run of nodes in order and adds into a
+// private [U][CW] table in LDS (plain read-modify-write: no races, fixed order); groups are then added in order.
 struct DgParams { int N, K, D, U; const float* gh; const float* theta; const int32_t* uid; int64_t uid_stride; float* slab; };
 
-__global__ void __launch_bounds__(512)
-dict_grad_kernel(const DgParams p, int CW) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [kDgGroups][U][CW]
-    const int nthreads = kDgGroups * CW;
-    for (int t = threadIdx.x; t < kDgGroups * p.U * CW; t += nthreads) lds[t] = 0.f;
+__global__ void __launch_bounds__(kBlock)
+dict_grad_kernel(const DgParams p, int CW, int NG) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NG][U][CW]
+    for (int t = threadIdx.x; t < NG * p.U * CW; t += kBlock) lds[t] = 0.f;
     __syncthreads();
     const int grp = threadIdx.x / CW, col = threadIdx.x % CW;
     const int64_t per_block = ((int64_t)p.N + gridDim.x - 1) / gridDim.x;
-    const int64_t m0 = (int64_t)blockIdx.x * per_block;
-    const int64_t m1 = m0 + per_block < p.N ? m0 + per_block : p.N;
-    if (col < p.D && m0 < m1) {
-        float th[4];                                  // this group's hops: grp, grp + 4, grp + 8, grp + 12
+    const int64_t b0 = (int64_t)blockIdx.x * per_block;
+    const int64_t b1 = b0 + per_block < p.N ? b0 + per_block : p.N;
+    if (grp < NG && col < p.D && b0 < b1) {
+        const int64_t per_grp = (b1 - b0 + NG - 1) / NG;
+        const int64_t m0 = b0 + grp * per_grp;
+        const int64_t m1 = m0 + per_grp < b1 ? m0 + per_grp : b1;
+        float th[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) th[j] = grp + kDgGroups * j < p.K ? p.theta[(grp + kDgGroups * j) * p.D + col] : 0.f;
+        for (int k = 0; k < 16; ++k) th[k] = k < p.K ? p.theta[k * p.D + col] : 0.f;
         float* acc = lds + (int64_t)grp * p.U * CW + col;
-        for (int64_t m = m0; m < m1; m += 4) {        // four nodes per trip: their loads do not wait for the LDS updates
-            float gv[4]; int uu[4][4];
+        for (int64_t m = m0; m < m1; m += 2) {       // two nodes per trip: their loads do not wait for the LDS updates
+            const float g0 = p.gh[m * p.D + col];
+            const float g1 = m + 1 < m1 ? p.gh[(m + 1) * p.D + col] : 0.f;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const bool ok = m + n < m1;
-                gv[n] = ok ? p.gh[(m + n) * p.D + col] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    uu[n][j] = (ok && grp + kDgGroups * j < p.K) ? p.uid[(m + n) * p.uid_stride + grp + kDgGroups * j] : -1;
+            for (int k = 0; k < 16; ++k) {
+                if (k >= p.K) break;
+                const int u0 = p.uid[m * p.uid_stride + k];                       // wave-uniform when CW >= 64
+                const int u1 = m + 1 < m1 ? p.uid[(m + 1) * p.uid_stride + k] : -1;
+                acc[u0 * CW] = fmaf(th[k], g0, acc[u0 * CW]);
+                if (u1 >= 0) acc[u1 * CW] = fmaf(th[k], g1, acc[u1 * CW]);
             }
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (uu[n][j] >= 0) acc[uu[n][j] * CW] = fmaf(th[j], gv[n], acc[uu[n][j] * CW]);
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < p.U * p.D; t += nthreads) {
+    for (int t = threadIdx.x; t < p.U * p.D; t += kBlock) {
         const int r = t / p.D, c = t - r * p.D;
         float v = 0.f;
-        for (int g = 0; g < kDgGroups; ++g) v += lds[((int64_t)g * p.U + r) * CW + c];
+        for (int g = 0; g < NG; ++g) v += lds[((int64_t)g * p.U + r) * CW + c];
         p.slab[((int64_t)blockIdx.x * p.U + r) * p.D + c] = v;
     }
 }
@@ -202,15 +197,21 @@ dict_grad_kernel(const DgParams p, int CW) {
 struct FinParams {
     int K, D, n0, nk, U, nseg, ndict_blocks, want_tab, want_th;
     const float* slab_tab; const float* slab_th; const float* slab_dict;
-    const int32_t* key_ptr; int NC; const int32_t* hop_seg;
+    const uint32_t* seg_key; const int32_t* hop_seg;
     float* gtable0; float* gtablek; float* gtheta; float* gdict;
     const float* alpha; const float* theta; float* galpha;
 };
 
+__device__ __forceinline__ int seg_lower_bound(const uint32_t* keys, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 __global__ void __launch_bounds__(1024)
 combine_finish_kernel(const FinParams p) {
     __shared__ float part[64][17];
-    int range[2];
+    __shared__ int range[2];
     const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int col = blockIdx.y * 16 + o;
     const bool col_ok = col < p.D;
@@ -225,18 +226,14 @@ combine_finish_kernel(const FinParams p) {
         if (slice == 0) for (int q = 0; q < 64; ++q) tot += part[q][o];
         return tot;
     };
-    // segments of (hop h, code c): [key_ptr[h*(NC+1)+c], key_ptr[h*(NC+1)+c+1]) clipped to the first nseg segments; codes the
-    // CSR never holds (c >= NC) have none
-    auto key_range = [&](int h, int c) {
-        range[0] = range[1] = 0;
-        if (c < p.NC) {
-            range[0] = min(p.key_ptr[h * (p.NC + 1) + c], p.nseg);
-            range[1] = min(p.key_ptr[h * (p.NC + 1) + c + 1], p.nseg);
-        }
+    auto key_range = [&](uint32_t key) {                                   // segments with exactly this (hop, code)
+        __syncthreads();
+        if (threadIdx.x == 0) { range[0] = seg_lower_bound(p.seg_key, p.nseg, key); range[1] = seg_lower_bound(p.seg_key, p.nseg, key + 1); }
+        __syncthreads();
     };
     if (r < p.n0) {
         if (!p.want_tab) return;
-        key_range(0, r);
+        key_range((uint32_t)r);
         const float tot = block_sum(p.slab_tab, range[0], range[1]);
         if (slice == 0 && col_ok) p.gtable0[(int64_t)r * p.D + col] = tot;
     } else if (r < p.n0 + p.nk) {
@@ -244,7 +241,7 @@ combine_finish_kernel(const FinParams p) {
         const int code = r - p.n0;
         float tot = 0.f;
         for (int h = 1; h < p.K; ++h) {
-            key_range(h, code);
+            key_range(((uint32_t)h << 16) | (uint32_t)code);
             tot += block_sum(p.slab_tab, range[0], range[1]);
         }
         if (slice == 0 && col_ok) p.gtablek[(int64_t)code * p.D + col] = tot;
@@ -290,8 +287,7 @@ int cs_shape(const kpgnn_combine_sorted_desc* d, int* vec, int* g) {
     int v = (d->D % 4 == 0) ? 4 : (d->D % 2 == 0 ? 2 : 1);
     auto al = [&](const void* q) { while (v > 1 && q && ((uintptr_t)q % (v * 4))) v >>= 1; };
     al(d->pre); al(d->gh); al(d->theta); al(d->gout); al(d->periph); al(d->ptab); al(d->g); al(d->gv); al(d->workspace);
-    for (int64_t s : {d->gout ? d->go_sn : 0, d->gout ? d->go_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
-                      d->pre_sn, d->pre_sk, d->g_sn, d->g_sk})
+    for (int64_t s : {d->gout ? d->go_sn : 0, d->gout ? d->go_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0})
         while (v > 1 && (s % v)) v >>= 1;
     const int lanes = (d->D + v - 1) / v;
     if (lanes > 64) return fail(KPGNN_ELIMIT, "combine_sorted: D=%d needs %d lanes > 64", d->D, lanes);
@@ -329,19 +325,20 @@ int cs_launch(const CsParams& p, hipStream_t s) {
     return cs_launch2<VEC, G, 0, false>(p, lds, s);
 }
 
-struct DictPlan { int CW, blocks; size_t lds; };
+struct DictPlan { int CW, NG, blocks; size_t lds; };
 
 bool dict_plan(int N, int D, int U, DictPlan* pl) {
-    if (D > 128 || U < 1) return false;
-    int cw = 16;
+    if (D > kBlock || U < 1) return false;
+    int cw = 1;
     while (cw < D) cw <<= 1;
-    const size_t lds = sizeof(float) * (size_t)kDgGroups * U * cw;
-    if (lds > 128 * 1024) return false;
-    int64_t blocks = ((int64_t)N + 63) / 64;                      // >= 64 nodes per block
-    const int64_t cap = (int64_t)device_facts().cu_count * 2;
-    if (blocks > cap) blocks = cap;
+    const size_t one = sizeof(float) * (size_t)U * cw;
+    if (one > 96 * 1024) return false;
+    int ng = kBlock / cw;
+    while (ng > 1 && one * ng > 96 * 1024) ng >>= 1;
+    int64_t blocks = ((int64_t)N + 32 * ng - 1) / (32 * ng);      // >= 32 nodes per group
+    if (blocks > device_facts().cu_count) blocks = device_facts().cu_count;
     if (blocks < 1) blocks = 1;
-    pl->CW = cw; pl->blocks = (int)blocks; pl->lds = lds;
+    pl->CW = cw; pl->NG = ng; pl->blocks = (int)blocks; pl->lds = one * ng;
     return true;
 }
 
@@ -369,7 +366,6 @@ extern "C" int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_st
     const bool want_tab = d->gtable0 != nullptr;
     const bool want_th = (d->gtheta != nullptr || d->galpha != nullptr) && d->theta != nullptr;
     KPGNN_REQUIRE(!want_tab || (d->n_code0 >= 1 && (d->K == 1 || (d->gtablek && d->n_codek >= 1))), "combine_sorted: missing gtable0/gtablek");
-    KPGNN_REQUIRE(!want_tab || (d->key_ptr && d->num_codes >= 1), "combine_sorted: table gradients need key_ptr / num_codes");
     KPGNN_REQUIRE(!d->galpha || d->alpha, "combine_sorted: galpha needs alpha");
     const bool want_dict = d->gdict != nullptr && d->n_dict > 0;
     KPGNN_REQUIRE(!want_dict || (d->uid && d->theta && d->gh && d->uid_stride >= d->K), "combine_sorted: dictionary gradient needs uid, theta, gh");
@@ -386,8 +382,6 @@ extern "C" int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_st
     p.gout = d->gout; p.go_sn = d->go_sn; p.go_sk = d->go_sk; p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     p.g = d->g; p.gv = d->gv;
-    p.pre_sn = d->pre_sn ? d->pre_sn : (int64_t)d->K * d->D; p.pre_sk = d->pre_sn ? d->pre_sk : d->D;
-    p.g_sn = d->g_sn ? d->g_sn : (int64_t)d->K * d->D; p.g_sk = d->g_sn ? d->g_sk : d->D;
     p.ent = d->entries; p.seg_ptr = d->seg_ptr; p.seg_key = d->seg_key; p.nseg = d->num_segments;
     p.slab_tab = want_tab ? ws : nullptr;
     p.slab_th = want_th ? ws + seg_rows : nullptr;
@@ -411,7 +405,7 @@ extern "C" int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_st
         q.N = d->N; q.K = d->K; q.D = d->D; q.U = d->n_dict; q.gh = d->gh; q.theta = d->theta; q.uid = d->uid;
         q.uid_stride = d->uid_stride; q.slab = slab_dict;
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)dict_grad_kernel, dpl.lds));
-        hipLaunchKernelGGL(dict_grad_kernel, dim3(dpl.blocks), dim3(kDgGroups * dpl.CW), dpl.lds, s, q, dpl.CW);
+        hipLaunchKernelGGL(dict_grad_kernel, dim3(dpl.blocks), dim3(kBlock), dpl.lds, s, q, dpl.CW, dpl.NG);
         KPGNN_LAUNCH_CHECK("dict_grad_kernel");
     }
     if (!want_tab && !want_th && !want_dict) return KPGNN_OK;
@@ -420,7 +414,7 @@ extern "C" int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_st
     f.U = want_dict ? d->n_dict : 0; f.nseg = d->num_segments; f.ndict_blocks = dpl.blocks;
     f.want_tab = want_tab ? 1 : 0; f.want_th = want_th ? 1 : 0;
     f.slab_tab = p.slab_tab; f.slab_th = p.slab_th; f.slab_dict = slab_dict;
-    f.key_ptr = d->key_ptr; f.NC = d->num_codes; f.hop_seg = d->hop_seg;
+    f.seg_key = d->seg_key; f.hop_seg = d->hop_seg;
     f.gtable0 = d->gtable0; f.gtablek = d->gtablek; f.gtheta = d->gtheta; f.gdict = d->gdict;
     f.alpha = d->alpha; f.theta = d->theta; f.galpha = d->galpha;
     const unsigned rows = (unsigned)(f.n0 + f.nk + 1 + f.U);

@@ -129,21 +129,6 @@ __global__ void hop_seg_kernel(const uint32_t* __restrict__ seg_key, const int32
     hop_seg[k] = lo;
 }
 
-// key_ptr[h * (NC + 1) + c] = first segment whose key >= (h, c), c = 0..NC: the segments of (hop h, code c) are
-// [key_ptr[h*(NC+1)+c], key_ptr[h*(NC+1)+c+1]); codes >= NC (the 0xFFFF rows without pairs) start at entry NC.
-__global__ void __launch_bounds__(kThreads)
-key_ptr_kernel(const uint32_t* __restrict__ seg_key, const int32_t* __restrict__ counts, int K, int NC, int32_t* __restrict__ key_ptr) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= K * (NC + 1)) return;
-    const uint32_t key = ((uint32_t)(t / (NC + 1)) << 16) | (uint32_t)(t % (NC + 1));
-    int lo = 0, hi = counts[1];
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_key[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    key_ptr[t] = lo;
-}
-
 struct SegWs { int32_t* cnt; uint32_t* mincode; uint64_t *keys_a, *keys_b; int32_t *flag, *idx; uint32_t* ekey; void* prim; size_t prim_bytes, total; };
 
 hipError_t plan(int64_t S, int64_t T, char* base, SegWs* w) {
@@ -187,19 +172,16 @@ extern "C" size_t kpgnn_csr_code_segments_workspace_bytes(int64_t N, int32_t K, 
 
 extern "C" int kpgnn_csr_code_segments(const int32_t* rowptr_dst, const uint16_t* code_dst, int64_t N, int32_t K, int64_t A,
                                        uint32_t* entries, int32_t* seg_ptr, uint32_t* seg_key, int32_t* hop_seg,
-                                       int32_t* counts, int32_t num_codes, int32_t* key_ptr, void* workspace,
-                                       size_t workspace_bytes, kpgnn_stream_t stream) {
+                                       int32_t* counts, void* workspace, size_t workspace_bytes, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(N >= 0 && K >= 1 && K <= 62 && A >= 0, "csr_code_segments: bad N=%lld K=%d A=%lld", (long long)N, K, (long long)A);
     const int64_t S = N * (int64_t)K, T = A + S;        // upper bound of the number of keys
     if (T >= ((int64_t)1 << 31)) return fail(KPGNN_ELIMIT, "csr_code_segments: A + N*K = %lld exceeds the int32 index range", (long long)T);
     KPGNN_REQUIRE(entries && seg_ptr && seg_key && hop_seg && counts, "csr_code_segments: NULL output");
-    KPGNN_REQUIRE(!key_ptr || (num_codes >= 1 && num_codes <= 65535), "csr_code_segments: bad num_codes=%d", num_codes);
     hipStream_t s = (hipStream_t)stream;
     if (S == 0) {
         KPGNN_HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
         KPGNN_HIP_TRY(hipMemsetAsync(seg_ptr, 0, sizeof(int32_t), s));
         KPGNN_HIP_TRY(hipMemsetAsync(hop_seg, 0, sizeof(int32_t) * (size_t)(K + 1), s));
-        if (key_ptr) KPGNN_HIP_TRY(hipMemsetAsync(key_ptr, 0, sizeof(int32_t) * (size_t)K * (num_codes + 1), s));
         return KPGNN_OK;
     }
     KPGNN_REQUIRE(rowptr_dst && (A == 0 || code_dst), "csr_code_segments: NULL CSR");
@@ -242,11 +224,5 @@ extern "C" int kpgnn_csr_code_segments(const int32_t* rowptr_dst, const uint16_t
     KPGNN_LAUNCH_CHECK("seg_emit_kernel");
     hipLaunchKernelGGL(hop_seg_kernel, dim3(1), dim3(64), 0, s, seg_key, counts, (int)K, hop_seg);
     KPGNN_LAUNCH_CHECK("hop_seg_kernel");
-    if (key_ptr) {
-        const int n = K * (num_codes + 1);
-        hipLaunchKernelGGL(key_ptr_kernel, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, seg_key, counts, (int)K,
-                           (int)num_codes, key_ptr);
-        KPGNN_LAUNCH_CHECK("key_ptr_kernel");
-    }
     return KPGNN_OK;
 }

@@ -53,18 +53,16 @@ class KHopCSR:
         seg_key = torch.empty(T, dtype=torch.int32, device=dev)
         hop_seg = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
         counts = torch.zeros(2, dtype=torch.int32, device=dev)
-        nc = max(self.max_code0, self.max_codek) + 1
-        key_ptr = torch.empty(self.K * (nc + 1), dtype=torch.int32, device=dev)
         nb = int(lib.kpgnn_csr_code_segments_workspace_bytes(self.N, self.K, self.A))
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_csr_code_segments(self.rowptr_dst.data_ptr(), self.code_dst.data_ptr(), self.N, self.K, self.A,
                                                    ent.data_ptr(), seg_ptr.data_ptr(), seg_key.data_ptr(), hop_seg.data_ptr(),
-                                                   counts.data_ptr(), nc, key_ptr.data_ptr(), ws.data_ptr(), ctypes.c_size_t(ws.numel()),
+                                                   counts.data_ptr(), ws.data_ptr(), ctypes.c_size_t(ws.numel()),
                                                    torch.cuda.current_stream(dev).cuda_stream), "kpgnn_csr_code_segments")
         ne, ns = counts.tolist()
         self._segs = dict(entries=ent[:ne].contiguous(), seg_ptr=seg_ptr[:ns + 1].contiguous(), seg_key=seg_key[:ns].contiguous(),
-                          hop_seg=hop_seg, hop_seg_host=hop_seg.tolist(), NE=ne, NS=ns, key_ptr=key_ptr, num_codes=nc)
+                          hop_seg=hop_seg, hop_seg_host=hop_seg.tolist(), NE=ne, NS=ns)
         return self._segs
 
     def active_pairs(self, k_active):

@@ -104,7 +104,7 @@ class DictPeripheral:
 
 
 def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None,
-                      xs=None, alphas=None, pre_hop_major=False):
+                      xs=None, alphas=None):
     """Launch kpgnn_aggregate_fwd.  x is [N,k,D], or None with xs = k per-hop [N,D] tensors (row stride shared).
     Returns (out or hout, pre or None)."""
     lib = _lib.load()
@@ -138,12 +138,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.n_dict = ptab.shape[0]
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
-    pre = None
-    if want_pre and pre_hop_major:     # S stored [K,N,D] (the sorted backward pre-pass walks the rows hop by hop), seen as [N,K,D]
-        pre = torch.empty((K, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
-        d.pre_sn, d.pre_sk = pre.stride(0), pre.stride(1)
-    elif want_pre:
-        pre = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
     d.pre = _ptr(pre)
     if theta is not None:
         out = torch.empty((N, D), dtype=torch.float32, device=dev)
@@ -335,15 +330,11 @@ def combine_sorted_raw(csr, segs, k_act, mode, pre, gout, theta, periph, ptab, u
         d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
     elif uid is not None and ptab is not None:
         d.ptab, d.uid, d.uid_stride, d.n_dict = ptab.data_ptr(), uid.data_ptr(), uid.stride(0), ptab.shape[0]
-    # g hop-major ([K,N,D] seen as [N,K,D]) like pre: rows written close in time share cache lines, and the gather that
-    # follows (kpgnn_aggregate_bwd, stride-based) finds the rows of one hop side by side
-    g = torch.empty((K, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
+    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
     gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
     d.g, d.gv = g.data_ptr(), _ptr(gv)
-    d.pre_sn, d.pre_sk, d.g_sn, d.g_sk = pre.stride(0), pre.stride(1), g.stride(0), g.stride(1)
     d.entries, d.seg_ptr, d.seg_key = segs["entries"].data_ptr(), segs["seg_ptr"].data_ptr(), segs["seg_key"].data_ptr()
     d.hop_seg, d.num_segments = segs["hop_seg"].data_ptr(), nseg
-    d.key_ptr, d.num_codes = segs["key_ptr"].data_ptr(), segs["num_codes"]
     gt0 = gtk = gth = gd = None
     if want_tables:
         nk = n_codek if K > 1 else 0
@@ -421,13 +412,8 @@ class KHopAggregate(torch.autograd.Function):
         if ptab is not None:
             ptab = ptab.contiguous()
         need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
-        # (the backward pre-pass of these epilogues walks the rows in (hop, code) order when the CSR has its segment list)
-        sorted_bwd = (need_pre and mode != MODE_GCN and k_act <= 16 and any(ctx.needs_input_grad)
-                      and csr.code_segments() is not None)
         out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre,
-                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None, alphas=alphas,
-                                     pre_hop_major=sorted_bwd)
-        ctx.sorted_bwd = sorted_bwd
+                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None, alphas=alphas)
         ctx.alphas = alphas
         ctx.csr, ctx.k_act, ctx.mode, ctx.uid = csr, k_act, mode, uid
         ctx.has_tables = table0 is not None
@@ -456,7 +442,7 @@ class KHopAggregate(torch.autograd.Function):
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
         tables_in_gather = False
-        segs = csr.code_segments() if ctx.sorted_bwd else None
+        segs = csr.code_segments() if ((fused or need_act) and mode != MODE_GCN and k_act <= 16) else None
         if segs is not None:
             # one call: g, theta / alpha gradient, edge-code table gradients and the dictionary gradient (rows visited in
             # (hop, code) order: the table gradients are segmented sums formed on the way, g is not read again)
