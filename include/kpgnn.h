@@ -83,20 +83,6 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
                     int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                     void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
-/* Code-sorted segment list of a built CSR (csrc/csr_segments.hip), for kpgnn_combine_sorted: the rows (node, hop) of
- * the batch in (hop, code, node) order, so that the table gradients become a segmented sum.
- *   entries  uint32[<= A + N*K][2]: (node, multiplicity | first << 31) per DISTINCT (node, hop, code); rows without
- *            pairs get one entry with code 0xFFFF and multiplicity 0; `first` marks the row's entry with the smallest code
- *   seg_ptr  int32[<= A + N*K + 1]: first entry of every segment (<= 32 entries of one (hop, code)); seg_ptr[NS] = NE
- *   seg_key  uint32[<= A + N*K]: hop << 16 | code of the segment (ascending)
- *   hop_seg  int32[K + 1]: number of segments of hops < k
- *   counts   int32[2]: NE (entries), NS (segments) - device memory; read them back once to size the consumers' slabs
- * K <= 62, codes <= 65534.  Integer work only: bitwise reproducible. */
-size_t kpgnn_csr_code_segments_workspace_bytes(int64_t N, int32_t K, int64_t A);
-int kpgnn_csr_code_segments(const int32_t* rowptr_dst, const uint16_t* code_dst, int64_t N, int32_t K, int64_t A,
-                            uint32_t* entries, int32_t* seg_ptr, uint32_t* seg_key, int32_t* hop_seg, int32_t* counts,
-                            void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
@@ -255,36 +241,6 @@ typedef struct kpgnn_combine_bwd_desc {
 
 size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D);
 int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t stream);
-
-/* The same backward pre-pass with the rows visited in the (hop, code) order of kpgnn_csr_code_segments, which makes the
- * edge-code table gradients a segmented sum done on the way (csrc/combine_sorted.hip): ONE call (a streaming launch, a
- * small dictionary-gradient launch, a finishing launch) replaces kpgnn_combine_bwd + kpgnn_table_grad and their slab
- * reductions, and g is never re-read.  Outputs (each optional unless noted):
- *   g [N,K,D] (required; every row written once), gv (dL/dP for a dense P),
- *   gtable0 [n_code0,D], gtablek [n_codek,D]   edge-code table gradients of the first K hops,
- *   gtheta [K,D] and / or galpha [D] (geometric combine: the theta gradient pushed through softmax_k(a(1-a)^k), alpha given),
- *   gdict [n_dict,D] = sum over (i,k) with uid[i,k] == u of theta[k,:]*gh[i,:]  (needs theta, gh, uid).
- * num_segments = hop_seg[K] (host copy) restricts the walk to the first K hops of a CSR built for K_csr >= K hops.
- * All sums are formed in a fixed order: bitwise reproducible. */
-typedef struct kpgnn_combine_sorted_desc {
-    int32_t N, K, D, mode;
-    const float* pre; const float* gh; const float* theta;
-    const float* gout; int64_t go_sn, go_sk;
-    const float* periph; int64_t p_sn, p_sk;
-    const float* ptab; const int32_t* uid; int64_t uid_stride; int32_t n_dict;
-    float* g; float* gv;
-    const uint32_t* entries; const int32_t* seg_ptr; const uint32_t* seg_key; const int32_t* hop_seg;
-    int32_t num_segments;
-    int32_t n_code0, n_codek;
-    float* gtable0; float* gtablek; float* gtheta;
-    const float* alpha; float* galpha;
-    float* gdict;
-    void* workspace; size_t workspace_bytes;   /* >= kpgnn_combine_sorted_workspace_bytes(num_segments, N, D, n_dict) */
-} kpgnn_combine_sorted_desc;
-
-size_t kpgnn_combine_sorted_workspace_bytes(int32_t num_segments, int32_t N, int32_t D, int32_t n_dict);
-int kpgnn_combine_sorted(const kpgnn_combine_sorted_desc* d, kpgnn_stream_t stream);
-
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-table gather-sum: out[m,:] = bias + sum_c table[col_offset[c] + idx[m,c], :].

@@ -148,22 +148,6 @@ class TgsDesc(ctypes.Structure):
     ]
 
 
-class CombineSortedDesc(ctypes.Structure):
-    _fields_ = [
-        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("mode", c_i32),
-        ("pre", c_vp), ("gh", c_vp), ("theta", c_vp),
-        ("gout", c_vp), ("go_sn", c_i64), ("go_sk", c_i64),
-        ("periph", c_vp), ("p_sn", c_i64), ("p_sk", c_i64),
-        ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64), ("n_dict", c_i32),
-        ("g", c_vp), ("gv", c_vp),
-        ("entries", c_vp), ("seg_ptr", c_vp), ("seg_key", c_vp), ("hop_seg", c_vp),
-        ("num_segments", c_i32), ("n_code0", c_i32), ("n_codek", c_i32),
-        ("gtable0", c_vp), ("gtablek", c_vp), ("gtheta", c_vp),
-        ("alpha", c_vp), ("galpha", c_vp), ("gdict", c_vp),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
-    ]
-
-
 class PoolDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("G", c_i32), ("D", c_i32), ("mode", c_i32),
@@ -194,11 +178,6 @@ SIGNATURES = {
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
-    "kpgnn_csr_code_segments_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i64]),
-    "kpgnn_csr_code_segments": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                               ctypes.c_size_t, c_vp]),
-    "kpgnn_combine_sorted_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
-    "kpgnn_combine_sorted": (ctypes.c_int, [ctypes.POINTER(CombineSortedDesc), c_vp]),
     "kpgnn_segment_pool_fwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
     "kpgnn_segment_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
     "kpgnn_stat_slot_bytes": (ctypes.c_size_t, [c_i32]),

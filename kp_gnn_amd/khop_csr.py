@@ -22,7 +22,7 @@ class KHopCSR:
     """int32 CSR by (dst,hop) and by (src,hop) of the active (edge,hop) pairs."""
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
-                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_segs", "_dis", "_apairs",
+                 "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
                  "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
@@ -30,40 +30,6 @@ class KHopCSR:
     def __init__(self):
         self._dis = None
         self._apairs = {}
-
-    def code_segments(self):
-        """The (hop, code)-sorted segment list of this CSR (kpgnn_csr_code_segments), built on first use and cached:
-        dict(entries, seg_ptr, seg_key, hop_seg (device int32 [K+1]), hop_seg_host (list), NE, NS), or None when the CSR
-        is outside the list's limits (K > 62 or a code of 65535).  Building reads two counters back (one host sync per
-        batch object): it cannot happen inside a hipGraph capture - run one eager step on the batch first."""
-        rec = getattr(self, "_segs", False)
-        if rec is not False:
-            return rec
-        if self.K > 62 or max(self.max_code0, self.max_codek) >= 65535 or self.N == 0:
-            self._segs = None
-            return None
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.KpgnnError("K-hop CSR: the code-sorted segment list is built on first use and needs a host sync; run "
-                                  "one eager forward+backward on the batch before capturing a hipGraph")
-        lib = _lib.load()
-        dev = self.device
-        T = self.A + self.N * self.K
-        ent = torch.empty((T, 2), dtype=torch.int32, device=dev)
-        seg_ptr = torch.empty(T + 1, dtype=torch.int32, device=dev)
-        seg_key = torch.empty(T, dtype=torch.int32, device=dev)
-        hop_seg = torch.empty(self.K + 1, dtype=torch.int32, device=dev)
-        counts = torch.zeros(2, dtype=torch.int32, device=dev)
-        nb = int(lib.kpgnn_csr_code_segments_workspace_bytes(self.N, self.K, self.A))
-        ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(lib.kpgnn_csr_code_segments(self.rowptr_dst.data_ptr(), self.code_dst.data_ptr(), self.N, self.K, self.A,
-                                                   ent.data_ptr(), seg_ptr.data_ptr(), seg_key.data_ptr(), hop_seg.data_ptr(),
-                                                   counts.data_ptr(), ws.data_ptr(), ctypes.c_size_t(ws.numel()),
-                                                   torch.cuda.current_stream(dev).cuda_stream), "kpgnn_csr_code_segments")
-        ne, ns = counts.tolist()
-        self._segs = dict(entries=ent[:ne].contiguous(), seg_ptr=seg_ptr[:ns + 1].contiguous(), seg_key=seg_key[:ns].contiguous(),
-                          hop_seg=hop_seg, hop_seg_host=hop_seg.tolist(), NE=ne, NS=ns)
-        return self._segs
 
     def active_pairs(self, k_active):
         """Number of active (edge,hop) pairs within the first k_active hops (== A for k_active == K).

@@ -310,66 +310,6 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
     return g, gv, gth
 
 
-def combine_sorted_raw(csr, segs, k_act, mode, pre, gout, theta, periph, ptab, uid, want_gv, want_tables, n_code0, n_codek,
-                        want_gtheta, alphas, want_gdict):
-    """Launch kpgnn_combine_sorted: g = dL/dS (+ gv), the edge-code table gradients, the theta (or alpha) gradient and
-    the dictionary gradient in one call.  gout is gh [N,D] when theta is given, else dL/dout [N,K,D].
-    Returns (g, gv, gtheta_or_galpha, gtable0, gtablek, gdict)."""
-    lib = _lib.load()
-    N, K, D = pre.shape
-    dev = pre.device
-    nseg = int(segs["hop_seg_host"][k_act])
-    d = _lib.CombineSortedDesc()
-    d.N, d.K, d.D, d.mode = N, K, D, mode
-    d.pre = pre.data_ptr()
-    if theta is not None:
-        d.gh, d.theta = gout.data_ptr(), theta.data_ptr()
-    else:
-        d.gout, d.go_sn, d.go_sk = gout.data_ptr(), gout.stride(0), gout.stride(1)
-    if periph is not None:
-        d.periph, d.p_sn, d.p_sk = periph.data_ptr(), periph.stride(0), periph.stride(1)
-    elif uid is not None and ptab is not None:
-        d.ptab, d.uid, d.uid_stride, d.n_dict = ptab.data_ptr(), uid.data_ptr(), uid.stride(0), ptab.shape[0]
-    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
-    gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
-    d.g, d.gv = g.data_ptr(), _ptr(gv)
-    d.entries, d.seg_ptr, d.seg_key = segs["entries"].data_ptr(), segs["seg_ptr"].data_ptr(), segs["seg_key"].data_ptr()
-    d.hop_seg, d.num_segments = segs["hop_seg"].data_ptr(), nseg
-    gt0 = gtk = gth = gd = None
-    if want_tables:
-        nk = n_codek if K > 1 else 0
-        gt0 = torch.empty((n_code0, D), dtype=torch.float32, device=dev)
-        gtk = torch.empty((nk, D), dtype=torch.float32, device=dev) if nk > 0 else None
-        d.n_code0, d.n_codek, d.gtable0, d.gtablek = n_code0, nk, gt0.data_ptr(), _ptr(gtk)
-    if want_gtheta and theta is not None:
-        if alphas is not None:
-            gth = torch.empty_like(alphas)
-            d.alpha, d.galpha = alphas.data_ptr(), gth.data_ptr()
-        else:
-            gth = torch.empty((K, D), dtype=torch.float32, device=dev)
-            d.gtheta = gth.data_ptr()
-    n_dict = 0
-    if want_gdict and uid is not None and ptab is not None and theta is not None:
-        n_dict = ptab.shape[0]
-        gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
-        d.gdict = gd.data_ptr()
-        d.uid, d.uid_stride, d.n_dict = uid.data_ptr(), uid.stride(0), n_dict
-    nb = int(lib.kpgnn_combine_sorted_workspace_bytes(nseg, N, D, n_dict))
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), nb
-    with torch.cuda.device(dev):
-        if _timer is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _lib.check(lib.kpgnn_combine_sorted(ctypes.byref(d), _stream(pre)), "kpgnn_combine_sorted")
-        if _timer is not None:
-            e1.record()
-            n_t = 2 + (gv is not None) + (theta is None)
-            _timer.records.append(("combine_sorted", 4 * N * K * D * n_t + (4 * N * D if theta is not None else 0)
-                                   + 8 * segs["NE"], e0, e1))
-    return g, gv, gth, gt0, gtk, gd
-
-
 class KHopAggregate(torch.autograd.Function):
     """out[N,k,D] (or hout[N,D] with a fused geometric combine) = epilogue(K-hop segmented sum).
 
@@ -440,59 +380,41 @@ class KHopAggregate(torch.autograd.Function):
         gtheta = gperiph = gdict = None
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if fused or need_act:
+            g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
+                                            want_gtheta=fused and ctx.needs_input_grad[5],
+                                            want_gv=fused and want_gperiph)
+            gperiph = gv if fused else (gout if want_gperiph else None)
+        else:
+            g = gout
+            gperiph = gout if want_gperiph else None
+        # --- table gradients (edge codes + peripheral dictionary), column-private kernel
         gt0 = gtk = None
         tables_in_gather = False
-        segs = csr.code_segments() if ((fused or need_act) and mode != MODE_GCN and k_act <= 16) else None
-        if segs is not None:
-            # one call: g, theta / alpha gradient, edge-code table gradients and the dictionary gradient (rows visited in
-            # (hop, code) order: the table gradients are segmented sums formed on the way, g is not read again)
-            g, gv, gtheta, gt0, gtk, gdict = combine_sorted_raw(
-                csr, segs, k_act, mode, pre, gout, theta, periph, ptab, uid, want_gv=fused and want_gperiph,
-                want_tables=want_tables, n_code0=ctx.n_code0, n_codek=ctx.n_codek,
-                want_gtheta=fused and ctx.needs_input_grad[5], alphas=ctx.alphas, want_gdict=want_gdict and fused)
-            gperiph = gv if fused else (gout if want_gperiph else None)
-            alpha_done = ctx.alphas is not None
-            if want_gdict and gdict is None:   # activation without fused combine: dL/dP = gout
-                r2 = table_grad_raw(csr, gout, 0, 0, edges=False, uid=uid, n_dict=ctx.n_dict)
+        if want_tables or want_gdict:
+            edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
+            dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
+            res = None
+            if edges_here or dict_here:
+                res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
+                                     uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
+                                     theta=theta if fused else None, gh=gout if fused else None)
+            if res is not None:
+                gt0, gtk, gdict = res
+            if want_tables and (res is None or not edges_here):
+                tables_in_gather = True
+            if want_gdict and gdict is None:  # activation without fused combine (or oversize tables): dL/dP = gout
+                r2 = table_grad_raw(csr, gout if not fused else (gout.unsqueeze(1) * theta.unsqueeze(0)),
+                                    0, 0, edges=False, uid=uid, n_dict=ctx.n_dict)
                 if r2 is None:
                     raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
-        else:
-            alpha_done = False
-            if fused or need_act:
-                g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
-                                                want_gtheta=fused and ctx.needs_input_grad[5],
-                                                want_gv=fused and want_gperiph)
-                gperiph = gv if fused else (gout if want_gperiph else None)
-            else:
-                g = gout
-                gperiph = gout if want_gperiph else None
-            # --- table gradients (edge codes + peripheral dictionary), column-private kernel
-            if want_tables or want_gdict:
-                edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
-                dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
-                res = None
-                if edges_here or dict_here:
-                    res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
-                                         uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
-                                         theta=theta if fused else None, gh=gout if fused else None)
-                if res is not None:
-                    gt0, gtk, gdict = res
-                if want_tables and (res is None or not edges_here):
-                    tables_in_gather = True
-                if want_gdict and gdict is None:  # activation without fused combine (or oversize tables): dL/dP = gout
-                    r2 = table_grad_raw(csr, gout if not fused else (gout.unsqueeze(1) * theta.unsqueeze(0)),
-                                        0, 0, edges=False, uid=uid, n_dict=ctx.n_dict)
-                    if r2 is None:
-                        raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
-                                              "pass a dense peripheral_attr instead")
-                    gdict = r2[2]
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
         if tables_in_gather:
             gt0, gtk = a0, ak
-        if gtheta is not None and ctx.alphas is not None and not alpha_done:   # d/dalphas through theta (geo_theta.hip)
+        if gtheta is not None and ctx.alphas is not None:   # d/dalphas through theta (geo_theta.hip), one tiny launch
             galpha = torch.empty_like(ctx.alphas)
             lib = _lib.load()
             with torch.cuda.device(galpha.device):

@@ -1009,101 +1009,3 @@ def test_segment_pool_vs_index_add(D, mean):
     assert torch.equal(out, segment_pool(xd, bd, 300, mean=mean))
     with pytest.raises(ValueError):
         segment_pool(xd, torch.flip(bd, [0]).contiguous(), 300)
-
-
-# ----------------------------------------------------------------------------- code-sorted segments + fused backward pre-pass
-@pytest.mark.parametrize("N,E,K,ncode,density", [(203, 3000, 6, 9, 0.3), (64, 20000, 3, 3, 0.5), (10, 0, 4, 3, 0.5), (500, 4000, 16, 60, 0.1)])
-def test_code_segments_match_the_edge_list(N, E, K, ncode, density):
-    """kpgnn_csr_code_segments: the merged (node, hop, code) entries with multiplicities, the dummy entries of rows
-    without pairs, the `first` flags, the (hop, code, node) order, segment lengths and the hop prefix table - against a
-    Counter over the raw edge list (integer: exact)."""
-    from collections import Counter
-    from kp_gnn_amd.khop_csr import KHopCSR
-    rng = np.random.default_rng(N + E)
-    ei = rng.integers(0, N, size=(2, E))
-    ea = rng.integers(1, ncode, size=(E, K)) * (rng.random((E, K)) < density)
-    csr = KHopCSR.build(torch.from_numpy(ei).to(_dev()), torch.from_numpy(ea).to(_dev()), N)
-    segs = csr.code_segments()
-    ent = segs["entries"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    sp, sk = segs["seg_ptr"].cpu().numpy(), segs["seg_key"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    want = Counter()
-    e, k = np.nonzero(ea)
-    for a, b in zip(e, k):
-        want[(int(ei[1][a]), int(b), int(ea[a, b]))] += 1
-    rows_with_pairs = {(i, h) for (i, h, _) in want}
-    got, firsts, order = Counter(), Counter(), []
-    assert sp[0] == 0 and sp[-1] == segs["NE"] and len(sk) == segs["NS"]
-    for s in range(segs["NS"]):
-        hop, code = int(sk[s] >> 16), int(sk[s] & 0xFFFF)
-        assert 1 <= sp[s + 1] - sp[s] <= 32
-        for j in range(sp[s], sp[s + 1]):
-            node, mw = int(ent[j, 0]), int(ent[j, 1])
-            mult, first = mw & 0x7FFFFFFF, mw >> 31
-            order.append((hop, code, node))
-            if code == 0xFFFF:
-                assert mult == 0 and first == 1 and (node, hop) not in rows_with_pairs
-            else:
-                got[(node, hop, code)] += mult
-            firsts[(node, hop)] += first
-    assert got == want
-    assert order == sorted(order) and len(set(order)) == len(order)
-    assert all(firsts[(i, h)] == 1 for i in range(N) for h in range(K))           # every row visited, written exactly once
-    hs = segs["hop_seg_host"]
-    assert hs[0] == 0 and hs[K] == segs["NS"]
-    for h in range(K):
-        assert all((sk[s] >> 16) < h + 1 for s in range(hs[h + 1])) and all((sk[s] >> 16) >= h for s in range(hs[h], segs["NS"]))
-
-
-@pytest.mark.parametrize("variant", ["fused_dict", "fused_dense", "fused_noperiph", "unfused_gelu", "prefix_k3", "relu_fused"])
-def test_combine_sorted_equals_two_kernel_path(variant):
-    """kpgnn_combine_sorted (rows in (hop, code) order: g, theta / alpha gradient, edge-code table gradients and the
-    dictionary gradient in one call) against kpgnn_combine_bwd + kpgnn_table_grad on the same operands."""
-    from kp_gnn_amd import ops
-    from kp_gnn_amd._lib import MODE_GCN, MODE_GINPLUS
-    from kp_gnn_amd.khop_csr import KHopCSR
-    dev = _dev()
-    g0 = torch.Generator().manual_seed(len(variant))
-    N, Kc, E, D, U = 700, 8, 9000, 104, 19
-    K = 3 if variant == "prefix_k3" else Kc
-    ei = torch.randint(0, N, (2, E), generator=g0)
-    ea = torch.randint(0, 6, (E, Kc), generator=g0) * (torch.rand(E, Kc, generator=g0) < 0.3)
-    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
-    segs = csr.code_segments()
-    pre = torch.randn(N, K, D, generator=g0).to(dev)
-    fused = variant != "unfused_gelu"
-    mode = MODE_GCN if variant == "relu_fused" else MODE_GINPLUS
-    theta = torch.rand(K, D, generator=g0).to(dev) if fused else None
-    gout = (torch.randn(N, D, generator=g0) if fused else torch.randn(N, K, D, generator=g0)).to(dev)
-    uid = torch.randint(0, U, (N, Kc), generator=g0, dtype=torch.int32).to(dev)[:, :K]
-    ptab = torch.randn(U, D, generator=g0).to(dev)
-    periph = torch.randn(N, K, D, generator=g0).to(dev) if variant == "fused_dense" else None
-    use_dict = variant in ("fused_dict", "prefix_k3", "relu_fused")
-    alphas = torch.randn(D, generator=g0).to(dev) if variant == "fused_dict" else None
-    g_ref, gv_ref, gth_ref = ops.combine_bwd_raw(mode, pre, gout, theta, periph, ptab if use_dict else None,
-                                                 uid if use_dict else None, want_gtheta=fused, want_gv=periph is not None)
-    t_ref = ops.table_grad_raw(csr, g_ref, 6, 6, edges=True, uid=uid if (use_dict and fused) else None,
-                               n_dict=U if (use_dict and fused) else 0, theta=theta if (use_dict and fused) else None,
-                               gh=gout if (use_dict and fused) else None, kernel=1)
-    g, gv, gth, gt0, gtk, gd = ops.combine_sorted_raw(csr, segs, K, mode, pre, gout, theta, periph, ptab if use_dict else None,
-                                                       uid if use_dict else None, want_gv=periph is not None, want_tables=True,
-                                                       n_code0=6, n_codek=6, want_gtheta=fused, alphas=alphas,
-                                                       want_gdict=use_dict and fused)
-    # rows without pairs are not read by the gather that follows, but both paths write them: compare everything
-    _close(g, g_ref, "g", rtol=1e-5, atol=1e-6)
-    if periph is not None:
-        _close(gv, gv_ref, "gv", rtol=1e-5, atol=1e-6)
-    _close(gt0, t_ref[0], "gtable0", rtol=2e-4, atol=2e-5)
-    if K > 1:
-        _close(gtk, t_ref[1], "gtablek", rtol=2e-4, atol=2e-5)
-    if use_dict and fused:
-        _close(gd, t_ref[2], "gdict", rtol=2e-4, atol=2e-5)
-    if fused:
-        if alphas is not None:
-            from kp_gnn_amd import _lib
-            lib = _lib.load()
-            ga = torch.empty_like(alphas)
-            _lib.check(lib.kpgnn_geo_theta_bwd(alphas.data_ptr(), theta.data_ptr(), gth_ref.contiguous().data_ptr(), K, D,
-                                               ga.data_ptr(), torch.cuda.current_stream().cuda_stream), "geo_theta_bwd")
-            _close(gth, ga, "galpha", rtol=2e-4, atol=2e-5)
-        else:
-            _close(gth, gth_ref, "gtheta", rtol=2e-4, atol=2e-5)
