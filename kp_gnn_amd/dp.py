@@ -51,8 +51,9 @@ def grad_views(model):
 
 
 def allreduce_mean(flat, world):
-    """Mean of the flat gradient bucket over ranks.  Equal shards per rank => the mean of local-mean-loss
-    gradients is the gradient of the global mean loss the reference computes on GPU 0 (train_ZINC.py:36,42)."""
+    """Mean of the flat gradient bucket over ranks.  EQUAL shards per rank only (bench.py's weak scaling): the mean of
+    local-mean-loss gradients is then the gradient of the global mean loss the reference computes on GPU 0
+    (train_ZINC.py:36,42).  Unequal shards: shard_loss_weight + allreduce_sum."""
     if world <= 1:
         return
     if flat.is_cuda and dist.get_backend() == "gloo":
@@ -61,6 +62,56 @@ def allreduce_mean(flat, world):
         torch.cuda.synchronize(flat.device)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world)
+
+
+def partition_by_pairs(pairs_per_graph, world):
+    """Shard the graphs of a global batch over `world` ranks balancing the ACTIVE (edge, hop) PAIRS, not the graph count:
+    the aggregation's work and traffic follow A (ZINC-like graphs range over 9-37 nodes and E ~ n^2).
+    Longest-processing-time greedy: graphs by descending weight, each to the currently lightest shard (ties: lowest rank).
+    Returns `world` lists of graph indices, each ascending (a shard keeps the batch's node order).  Deterministic."""
+    w = [int(v) for v in pairs_per_graph]
+    order = sorted(range(len(w)), key=lambda i: (-w[i], i))
+    shards, load = [[] for _ in range(world)], [0] * world
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        shards[r].append(i)
+        load[r] += w[i]
+    return [sorted(sh) for sh in shards]
+
+
+def shard_loss_weight(local_graphs, global_graphs):
+    """Factor for a rank's MEAN loss over its own graphs so that the SUM all-reduce of the gradients (allreduce_sum) is the
+    gradient of the mean loss over the global batch, which is what the reference computes on GPU 0 after gathering the
+    replicas' outputs (train_ZINC.py:34-36,42): sum_r (n_r / G) * mean_r == (1 / G) * sum_g loss_g."""
+    return float(local_graphs) / float(global_graphs)
+
+
+def allreduce_sum(flat, world):
+    """Sum of the flat gradient bucket over ranks (unequal shards: every rank scaled its loss by shard_loss_weight)."""
+    if world <= 1:
+        return
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(flat.device)     # (rehearsal path only, see allreduce_mean)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
+def select_graphs(node_ptr, edge_ptr, edge_index, edge_attr, x, idx):
+    """Raw graphs (CSR-style concatenation, local node ids; the inputs of batch.collate_khop) restricted to the graphs
+    `idx`, in that order: a rank's shard of a global batch."""
+    import numpy as np
+    nps, eps, eis, eas, xs = [0], [0], [], [], []
+    for g in idx:
+        n0, n1, e0, e1 = int(node_ptr[g]), int(node_ptr[g + 1]), int(edge_ptr[g]), int(edge_ptr[g + 1])
+        nps.append(nps[-1] + n1 - n0)
+        eps.append(eps[-1] + e1 - e0)
+        eis.append(edge_index[:, e0:e1])
+        if edge_attr is not None:
+            eas.append(edge_attr[e0:e1])
+        xs.append(x[n0:n1])
+    cat = np.concatenate
+    return (np.array(nps, dtype=np.int64), np.array(eps, dtype=np.int64),
+            np.ascontiguousarray(cat(eis, axis=1)) if eis else np.zeros((2, 0), dtype=np.int64),
+            np.ascontiguousarray(cat(eas)) if eas else None, np.ascontiguousarray(cat(xs)) if xs else x[:0])
 
 
 def broadcast_model(model, src=0):
