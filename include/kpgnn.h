@@ -436,6 +436,29 @@ typedef struct kpgnn_pool_desc {
 int kpgnn_segment_pool_fwd(const kpgnn_pool_desc* d, kpgnn_stream_t stream);
 int kpgnn_segment_pool_bwd(const kpgnn_pool_desc* d, kpgnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Projected peripheral-feature tables (csrc/enc_tables.hip): for every encoder e (a FeatureConcatEncoder: per-column
+ * nn.Embedding -> concat -> Linear, layers/feature_encoder.py:37-67, gated by squash(pew / pcw), models/GNNs.py:172-179 /
+ * :393-400 / :637-644) and every component c of it
+ *     table[rows of c, :] = squash(gate_e) * Emb_c.weight @ W_e[:, cH:(c+1)H]^T        bias = sum_e squash(gate_e)*mult_e*b_e
+ * so that the features are one gather-sum over `table` (kpgnn_table_gather_sum).  One launch per direction instead of
+ * ~14 + ~28 framework launches on tiny tensors.  Components are listed encoder by encoder; H <= 256; <= 16 components,
+ * <= 4 encoders.  enc_squash: 0 sigmoid (GNN, GNNPrime), 1 tanh (GNNPlus).  enc_mult: how many index columns share the
+ * encoder's bias (T edge types for the edge encoder, 1 for the configuration encoder).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_enc_tables_desc {
+    int32_t H, num_components, num_encoders;
+    const float* comp_emb[16]; int32_t comp_rows[16]; int32_t comp_encoder[16];
+    const float* enc_w[4]; const float* enc_b[4]; const float* enc_gate[4]; float enc_mult[4]; int32_t enc_squash[4];
+    float* table; float* pre; float* bias;       /* forward outputs: [R,H], [R,H] (un-gated, kept for backward), [H] */
+    const float* gtable; const float* gbias;     /* backward inputs (plus pre) */
+    float* comp_gemb[16];                        /* backward outputs: like comp_emb */
+    float* enc_gw[4]; float* enc_gb[4]; float* enc_ggate[4];
+} kpgnn_enc_tables_desc;
+
+int kpgnn_enc_tables_fwd(const kpgnn_enc_tables_desc* d, kpgnn_stream_t stream);
+int kpgnn_enc_tables_bwd(const kpgnn_enc_tables_desc* d, kpgnn_stream_t stream);
+
 /* Identifier of the capture the stream is part of (hipStreamGetCaptureInfo), 0 when it is not capturing: lets a
  * caller that zeroes its statistics slots once per step put that memset into every graph it captures. */
 int kpgnn_stream_capture_id(kpgnn_stream_t stream, uint64_t* id);

@@ -148,6 +148,17 @@ class TgsDesc(ctypes.Structure):
     ]
 
 
+class EncTablesDesc(ctypes.Structure):
+    _fields_ = [
+        ("H", c_i32), ("num_components", c_i32), ("num_encoders", c_i32),
+        ("comp_emb", c_vp * 16), ("comp_rows", c_i32 * 16), ("comp_encoder", c_i32 * 16),
+        ("enc_w", c_vp * 4), ("enc_b", c_vp * 4), ("enc_gate", c_vp * 4), ("enc_mult", ctypes.c_float * 4),
+        ("enc_squash", c_i32 * 4),
+        ("table", c_vp), ("pre", c_vp), ("bias", c_vp), ("gtable", c_vp), ("gbias", c_vp),
+        ("comp_gemb", c_vp * 16), ("enc_gw", c_vp * 4), ("enc_gb", c_vp * 4), ("enc_ggate", c_vp * 4),
+    ]
+
+
 class PoolDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("G", c_i32), ("D", c_i32), ("mode", c_i32),
@@ -178,6 +189,8 @@ SIGNATURES = {
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
+    "kpgnn_enc_tables_fwd": (ctypes.c_int, [ctypes.POINTER(EncTablesDesc), c_vp]),
+    "kpgnn_enc_tables_bwd": (ctypes.c_int, [ctypes.POINTER(EncTablesDesc), c_vp]),
     "kpgnn_segment_pool_fwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
     "kpgnn_segment_pool_bwd": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_vp]),
     "kpgnn_stat_slot_bytes": (ctypes.c_size_t, [c_i32]),

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .layers.gine import GINEConv
-from .ops import DictPeripheral, embedding_rows, segment_pool, table_gather_sum
+from .ops import DictPeripheral, embedding_rows, enc_tables, segment_pool, table_gather_sum
 from .ops_dense import JKConcatLinear, batch_norm_act
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
@@ -293,20 +293,29 @@ class _KHopBody(nn.Module):
         if not (use_e or use_c):
             return like.new_zeros(num_nodes, self.K, self._periph_width)
         W = self._periph_width
-        tables, sizes, bias = [], [], 0
+        kind = 1 if self._gate is torch.tanh else (0 if self._gate is torch.sigmoid else -1)
+        encs, sizes = [], []
         if use_e:
-            enc, g = self.peripheral_edge_embedding, self._gate(self.pew)
-            T = pea.shape[-2]
-            tables.append(_projected_tables(enc, g))
+            enc = self.peripheral_edge_embedding
+            encs.append((enc, self.pew, pea.shape[-2]))
             sizes.extend(emb.num_embeddings for emb in enc.embedding_list)
-            bias = bias + g * T * enc.proj.bias
         if use_c:
-            enc, g = self.peripheral_configuration_embedding, self._gate(self.pcw)
-            tables.append(_projected_tables(enc, g))
+            enc = self.peripheral_configuration_embedding
+            encs.append((enc, self.pcw, 1))
             sizes.extend(emb.num_embeddings for emb in enc.embedding_list)
-            bias = bias + g * enc.proj.bias
+        if like.is_cuda and like.dtype == torch.float32 and kind >= 0 and W <= 256 and \
+                all(e.padding_idx is None for enc, _, _ in encs for e in enc.embedding_list):
+            # one launch per direction for ALL projected tables, gates and biases (csrc/enc_tables.hip)
+            table, bias = enc_tables(kind, [(enc.proj.weight, enc.proj.bias, gate, mult, [e.weight for e in enc.embedding_list])
+                                            for enc, gate, mult in encs])
+        else:
+            tables, bias = [], 0
+            for enc, gate, mult in encs:
+                g = self._gate(gate)
+                tables.append(_projected_tables(enc, g))
+                bias = bias + g * mult * enc.proj.bias
+            table = torch.cat(tables, dim=0)
         idx, col_offset, uidx, uid = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
-        table = torch.cat(tables, dim=0)
         if uidx is not None:
             # dictionary form: the distinct index tuples are few (25 for a 2048-molecule batch), so P is a
             # [U,W] table + a static int32 uid per (node,hop); the layers' kernels read / differentiate that

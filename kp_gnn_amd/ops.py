@@ -688,3 +688,83 @@ def segment_pool(x, batch, num_graphs, mean=False):
     """Sum / mean readout of [N,D] node rows per graph on the HIP kernels (fp32 device tensors, int64 sorted batch)."""
     _require_cuda(x, batch)
     return SegmentPool.apply(x, batch.long() if batch.dtype != torch.int64 else batch, graph_ptr_of(batch, num_graphs), num_graphs, mean)
+
+
+# ------------------------------------------------------------------------------------------------ projected tables
+class EncTables(torch.autograd.Function):
+    """(table [R,H], bias [H]) of the projected peripheral-feature tables (kpgnn_enc_tables_*): for encoder e with
+    components c:  table[rows of c] = squash(gate_e) * Emb_c.weight @ W_e[:, cH:(c+1)H]^T,  bias = sum_e squash(gate_e) *
+    mult_e * b_e.  One launch per direction.  Arguments: squash kind (0 sigmoid / 1 tanh), the encoders' multiplicities and
+    component counts, then per encoder (proj.weight, proj.bias, gate) and the embedding weights encoder by encoder."""
+
+    @staticmethod
+    def forward(ctx, squash, mults, ncomps, *tensors):
+        lib = _lib.load()
+        ne = len(ncomps)
+        enc_t, embs = tensors[:3 * ne], tensors[3 * ne:]
+        _require_cuda(*tensors)
+        H = embs[0].shape[1]
+        dev = embs[0].device
+        embs = [e.contiguous() for e in embs]
+        enc_t = [t.contiguous() for t in enc_t]
+        R = sum(e.shape[0] for e in embs)
+        out = torch.empty((2, R, H), dtype=torch.float32, device=dev)       # table, pre
+        bias = torch.empty((H,), dtype=torch.float32, device=dev)
+        d = EncTables._desc(squash, mults, ncomps, enc_t, embs, H)
+        d.table, d.pre, d.bias = out[0].data_ptr(), out[1].data_ptr(), bias.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_enc_tables_fwd(ctypes.byref(d), _stream(bias)), "kpgnn_enc_tables_fwd")
+        ctx.save_for_backward(out, *enc_t, *embs)
+        ctx.meta = (squash, tuple(mults), tuple(ncomps), H)
+        return out[0], bias
+
+    @staticmethod
+    def _desc(squash, mults, ncomps, enc_t, embs, H):
+        d = _lib.EncTablesDesc()
+        d.H, d.num_components, d.num_encoders = H, len(embs), len(ncomps)
+        c = 0
+        for e, n in enumerate(ncomps):
+            w, b, gate = enc_t[3 * e:3 * e + 3]
+            assert tuple(w.shape) == (H, n * H) and b.numel() == H and gate.numel() == 1
+            d.enc_w[e], d.enc_b[e], d.enc_gate[e] = w.data_ptr(), b.data_ptr(), gate.data_ptr()
+            d.enc_mult[e], d.enc_squash[e] = float(mults[e]), int(squash)
+            for _ in range(n):
+                assert embs[c].shape[1] == H
+                d.comp_emb[c], d.comp_rows[c], d.comp_encoder[c] = embs[c].data_ptr(), embs[c].shape[0], e
+                c += 1
+        assert c == len(embs)
+        return d
+
+    @staticmethod
+    def backward(ctx, gtable, gbias):
+        out, *rest = ctx.saved_tensors
+        squash, mults, ncomps, H = ctx.meta
+        ne = len(ncomps)
+        enc_t, embs = rest[:3 * ne], rest[3 * ne:]
+        lib = _lib.load()
+        dev = out.device
+        gtable = gtable.contiguous() if gtable is not None else torch.zeros_like(out[0])
+        gbias = gbias.contiguous() if gbias is not None else torch.zeros(H, dtype=torch.float32, device=dev)
+        d = EncTables._desc(squash, mults, ncomps, enc_t, embs, H)
+        d.pre, d.gtable, d.gbias = out[1].data_ptr(), gtable.data_ptr(), gbias.data_ptr()
+        g_enc = []
+        for e in range(ne):
+            gw, gb, gg = torch.empty_like(enc_t[3 * e]), torch.empty_like(enc_t[3 * e + 1]), torch.empty_like(enc_t[3 * e + 2])
+            d.enc_gw[e], d.enc_gb[e], d.enc_ggate[e] = gw.data_ptr(), gb.data_ptr(), gg.data_ptr()
+            g_enc += [gw, gb, gg]
+        g_emb = [torch.empty_like(e) for e in embs]
+        for c, g in enumerate(g_emb):
+            d.comp_gemb[c] = g.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_enc_tables_bwd(ctypes.byref(d), _stream(gtable)), "kpgnn_enc_tables_bwd")
+        return (None, None, None, *g_enc, *g_emb)
+
+
+def enc_tables(squash, encoders):
+    """encoders: list of (proj_weight [H, C*H], proj_bias [H], gate_raw [1], multiplicity, [Emb_c.weight ...]).
+    Returns (table [R,H], bias [H])."""
+    mults = [m for (_, _, _, m, _) in encoders]
+    ncomps = [len(embs) for (_, _, _, _, embs) in encoders]
+    enc_t = [t for (w, b, g, _, _) in encoders for t in (w, b, g)]
+    embs = [e for (_, _, _, _, es) in encoders for e in es]
+    return EncTables.apply(squash, mults, ncomps, *enc_t, *embs)

@@ -1009,3 +1009,42 @@ def test_segment_pool_vs_index_add(D, mean):
     assert torch.equal(out, segment_pool(xd, bd, 300, mean=mean))
     with pytest.raises(ValueError):
         segment_pool(xd, torch.flip(bd, [0]).contiguous(), 300)
+
+
+@pytest.mark.parametrize("H,kind", [(104, 1), (13, 0), (18, 0), (256, 1)])
+def test_enc_tables_vs_framework_ops(H, kind):
+    """kpgnn_enc_tables_*: the projected peripheral tables, gates and biases of both encoders in one launch per direction,
+    against the op-by-op formulation (gate * Emb_c.weight @ W_c^T per component; models/GNNs.py:393-400,
+    feature_encoder.py:62-67): values and every gradient (embeddings, proj weight / bias, gate parameters)."""
+    from kp_gnn_amd import body as B
+    from kp_gnn_amd.ops import enc_tables
+    dev = _dev()
+    torch.manual_seed(H)
+    gate_fn = torch.tanh if kind == 1 else torch.sigmoid
+    enc_e = B.FeatureConcatEncoder([5, 51], H).to(dev)
+    enc_c = B.FeatureConcatEncoder([51] * 7, H).to(dev)
+    pew, pcw = torch.nn.Parameter(torch.randn(1, device=dev)), torch.nn.Parameter(torch.randn(1, device=dev))
+    wt = torch.randn(5 + 51 + 7 * 51, H, device=dev)
+    wb = torch.randn(H, device=dev)
+    params = list(enc_e.parameters()) + list(enc_c.parameters()) + [pew, pcw]
+
+    def ref():
+        ge, gc = gate_fn(pew), gate_fn(pcw)
+        table = torch.cat([B._projected_tables(enc_e, ge), B._projected_tables(enc_c, gc)], 0)
+        bias = ge * 3 * enc_e.proj.bias + gc * enc_c.proj.bias
+        return table, bias
+
+    def hip():
+        return enc_tables(kind, [(enc_e.proj.weight, enc_e.proj.bias, pew, 3, [e.weight for e in enc_e.embedding_list]),
+                                 (enc_c.proj.weight, enc_c.proj.bias, pcw, 1, [e.weight for e in enc_c.embedding_list])])
+    res = []
+    for fn in (ref, hip):
+        for prm in params:
+            prm.grad = None
+        table, bias = fn()
+        ((table * wt).sum() + (bias * wb).sum()).backward()
+        res.append((table.detach().clone(), bias.detach().clone(), [prm.grad.clone() for prm in params]))
+    _close(res[1][0], res[0][0], "table", rtol=2e-4, atol=2e-5)
+    _close(res[1][1], res[0][1], "bias", rtol=2e-4, atol=2e-5)
+    for i, (a, b) in enumerate(zip(res[1][2], res[0][2])):
+        _close(a, b, f"grad[{i}]", rtol=3e-4, atol=3e-5)
