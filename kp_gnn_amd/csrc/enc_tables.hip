@@ -105,18 +105,29 @@ __global__ void __launch_bounds__(256) enc_tables_bwd_kernel(const EncParams p) 
         const float raw = e.gate_raw[0];
         const float g = squash(raw, e.squash);
         // d/dg = sum_{r in e, o} gtable[r,o] * pre[r,o] + sum_o gbias[o] * mult * b[o]   (pre: the un-gated tables of the forward)
+        // (all 256 threads stride over the encoder's rows * H elements, eight independent loads per trip: a per-column loop
+        //  over the rows was one dependent load chain of ~360 steps - 90 us for a 150 KB reduction)
         float acc = 0.f;
-        if (t < H)
-            for (int r = e.row0; r < e.row0 + e.rows; ++r) acc = fmaf(p.gtable[(int64_t)r * H + t], p.pre[(int64_t)r * H + t], acc);
+        {
+            const int64_t base = (int64_t)e.row0 * H, n = (int64_t)e.rows * H;
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int64_t i = t;
+            for (; i + 7 * 256 < n; i += 8 * 256) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] = fmaf(p.gtable[base + i + u * 256], p.pre[base + i + u * 256], a8[u]);
+            }
+            for (; i < n; i += 256) a8[0] = fmaf(p.gtable[base + i], p.pre[base + i], a8[0]);
+            acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        }
         if (t < H) {
             acc = fmaf(p.gbias[t] * e.mult, e.b[t], acc);
             e.gb[t] = g * e.mult * p.gbias[t];
         }
-        red[t] = t < H ? acc : 0.f;
+        red[t] = acc;
         __syncthreads();
         if (t == 0) {
             float tot = 0.f;
-            for (int i = 0; i < H; ++i) tot += red[i];
+            for (int i = 0; i < 256; ++i) tot += red[i];
             e.ggate[0] = tot * squash_grad(raw, e.squash);
         }
     }

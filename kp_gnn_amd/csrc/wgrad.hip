@@ -108,6 +108,14 @@ wgrad_kernel(const WgPair pp, int nprob) {
     if (nprob > 1) wgrad_problem<TI>(pp.q[1]);
 }
 
+// Blocks of a launch: every block writes a full O x I partial to the slab, so a small batch must not spread its few rows
+// over 512 blocks (N = 1.5k: 44 MB of slab written and re-read for 1.2 MB of operands); >= 32 rows per block.
+int wgrad_grid(int64_t N) {
+    int64_t g = (N + 31) / 32;
+    if (g > kWgradBlocks) g = kWgradBlocks;
+    return (int)(g < 1 ? 1 : g);
+}
+
 int wgrad_check(const kpgnn_wgrad_desc* d, const char* who) {
     KPGNN_REQUIRE(d != nullptr, "%s: NULL descriptor", who);
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "%s: bad N=%lld O=%d I=%d", who, (long long)d->N, d->O, d->I);
@@ -160,8 +168,7 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
     float* slab = (float*)d->workspace;
     WgPair pp;
     pp.q[0] = pp.q[1] = wgrad_params(d, slab, nw + d->O, 0);
-    const int64_t pairs = (d->N + 1) / 2;
-    const int grid = (int)(pairs < kWgradBlocks ? pairs : kWgradBlocks);
+    const int grid = wgrad_grid(d->N);
     hipStream_t s = (hipStream_t)stream;
     rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
     if (rc != KPGNN_OK) return rc;
@@ -182,8 +189,7 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
     WgPair pp;
     pp.q[0] = wgrad_params(a, slab, 2 * one, 0);
     pp.q[1] = wgrad_params(b, slab, 2 * one, one);
-    const int64_t pairs = (a->N + 1) / 2;
-    const int grid = (int)(pairs < kWgradBlocks ? pairs : kWgradBlocks);
+    const int grid = wgrad_grid(a->N);
     hipStream_t s = (hipStream_t)stream;
     rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
     if (rc != KPGNN_OK) return rc;
