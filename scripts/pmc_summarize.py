@@ -1,11 +1,14 @@
 """Turns rocprofv3 --pmc counter_collection.csv files into the per-kernel JSON summaries kept under profiles/.
 
-  python scripts/pmc_summarize.py traffic  <fetch_dir> <write_dir> <out.json> <workload_key>
+  python scripts/pmc_summarize.py traffic  <fetch_dir> <write_dir> <out.json> <workload_key> [csrc_digest]
   python scripts/pmc_summarize.py mfma     <pmc_dir> <out.json>
+  python scripts/pmc_summarize.py sq       <pmc_dir> <out.json>
 
 traffic: HBM bytes per launch = 2 x FETCH_SIZE(KB) x 1024 + WRITE_SIZE(KB) x 1024 (gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md, HBM section: 16-B-per-lane streaming reads are tallied at half), averaged
 over the launches of each kernel.
+sq: per kernel, averages of the SQ wave counters of one --pmc pass (SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY,
+SQ_ACTIVE_INST_ANY, SQ_INSTS_VALU, SQ_BUSY_CYCLES ...) and the derived wait fraction SQ_WAIT_ANY / SQ_WAVE_CYCLES.
 mfma: per kernel, sums of SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 and
 GRBM_GUI_ACTIVE and the derived matrix-core busy fraction.
 """
@@ -51,7 +54,24 @@ def main():
                        "FETCH_SIZE(KB) x 1024 (16-B-per-lane streaming reads are tallied at half) + WRITE_SIZE(KB) x 1024.",
                "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 4 --warmup 2 "
                           "--no-cpu-baseline --no-roofline --no-graph   (and the same with --pmc WRITE_SIZE)",
-               "workload_key": key, "kernels": res}
+               "workload_key": key, "csrc_digest": sys.argv[6] if len(sys.argv) > 6 else None, "kernels": res}
+    elif mode == "sq":
+        rows, out = load(sys.argv[2]), sys.argv[3]
+        res = {}
+        for k, c in sorted(rows.items()):
+            if not k.endswith("_kernel") or "SQ_WAVE_CYCLES" not in c:
+                continue
+            e = {"launches_sampled": len(c["SQ_WAVE_CYCLES"])}
+            for name, vals in sorted(c.items()):
+                e[name + "_avg"] = round(sum(vals) / len(vals), 1)
+            if e.get("SQ_WAVE_CYCLES_avg", 0) > 0 and "SQ_WAIT_ANY_avg" in e:
+                e["wait_frac"] = round(e["SQ_WAIT_ANY_avg"] / e["SQ_WAVE_CYCLES_avg"], 4)
+            if e.get("SQ_WAVE_CYCLES_avg", 0) > 0 and "SQ_ACTIVE_INST_ANY_avg" in e:
+                e["issue_frac"] = round(e["SQ_ACTIVE_INST_ANY_avg"] / e["SQ_WAVE_CYCLES_avg"], 4)
+            res[k] = e
+        doc = {"note": "SQ wave counters of one rocprofv3 --pmc pass (kernel-trace only, eager launches of the default bench "
+                       "step): wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of wave-cycles spent in s_waitcnt), issue_frac = "
+                       "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES.", "kernels": res}
     else:
         rows, out = load(sys.argv[2]), sys.argv[3]
         res = {}
