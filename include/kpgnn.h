@@ -83,6 +83,13 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
                     int32_t nodes_per_tile, int32_t* tile_ptr, uint32_t* tile_pack,
                     void* workspace, size_t workspace_bytes, kpgnn_stream_t stream);
 
+/* Hop-prefix copy of the table-gradient entry list: the entries of (tile_ptr, tile_pack) with hop < k, in the same
+ * order.  out_ptr int32[num_tiles+1], out_pack uint32[>= tile_ptr[num_tiles]], scratch int32[num_tiles].  A layer that
+ * aggregates k < K hops (models/GNNs.py:421-423) hands kpgnn_table_grad this copy: the kernel splits a tile's list
+ * among its waves by position, and inactive entries would leave most waves idle.  Static per batch and k. */
+int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t k,
+                           int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
@@ -207,11 +214,43 @@ typedef struct kpgnn_table_grad_desc {
      * wide rows to the register walk), 1 = force the walk, 2 = force the count-matrix kernel.  The parity tests
      * compare the two. */
     int32_t kernel;
+    /* Optional (walk kernel): the dictionary entries of every tile sorted by dictionary row, from kpgnn_dict_tile_pack
+     * on the same uid / nodes_per_tile with dict_pack_K >= K hops (one list serves every layer: hops >= K are skipped).
+     * Equal rows then leave the registers once per run, and a row belongs to one wave at a time (no float atomics:
+     * bitwise reproducible).  Without it a dictionary gradient goes to the count-matrix kernel. */
+    const uint32_t* dict_pack;
+    int32_t dict_pack_K;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
                                         int32_t n_code0, int32_t n_codek, int32_t n_dict);
 int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream);
+/* pack[tile*64 + j] = uid<<8 | node_in_tile<<3 | hop for the (node, hop) entries of a tile of nodes_per_tile nodes
+ * (nodes_per_tile * K <= 64, K <= 8), sorted by uid; unused places hold 0xFFFFFFFF.  pack: uint32[ceil(N/npt) * 64].
+ * A one-off per batch (the ids are data): the reference recomputes nothing like it - its embedding backward sorts the
+ * same ids on every step (aten embedding_dense_backward under models/GNNs.py:172-179). */
+int kpgnn_dict_tile_pack(const int32_t* uid, int64_t uid_stride, int32_t N, int32_t K, int32_t nodes_per_tile,
+                         uint32_t* pack, kpgnn_stream_t stream);
+
+/* Peripheral-dictionary gradient under the fused geometric combine, from gh alone (no [N,K,D] operand):
+ *   gdict[u,:] = sum_k theta[k,:] * sum over nodes i with uid[i,k] == u of gh[i,:]
+ * (the same sums as kpgnn_table_grad's dict_src 1, which stays as the path for shapes this kernel does not take:
+ * kpgnn_dict_grad_workspace_bytes returns 0 unless K <= 8, D even and <= 128 and n_dict*K*D*4 B + 32 KB fit LDS).
+ * One wave per hop, accumulator rows (u, hop) private to a wave: no atomics, bitwise reproducible.
+ * Replaces the embedding_dense_backward calls under models/GNNs.py:393-400 for the dictionary form of the features. */
+typedef struct kpgnn_dict_grad_desc {
+    int32_t N, K, D, n_dict;
+    const int32_t* uid;         /* device [N, uid_stride]: dictionary row of (node, hop), values in [0, n_dict) */
+    int64_t uid_stride;
+    const float* theta;         /* device [K, D] */
+    const float* gh;            /* device [N, D] contiguous */
+    float* gdict;               /* device [n_dict, D] (overwritten) */
+    void* workspace;            /* device, >= kpgnn_dict_grad_workspace_bytes(N, K, D, n_dict) */
+    size_t workspace_bytes;
+} kpgnn_dict_grad_desc;
+
+size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t n_dict);
+int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t stream);
 
 /* Backward pre-pass of the fused epilogue (elementwise, streaming):  with v = act(S) + P,
  *   gv[i,k,:] = theta[k,:] * gh[i,:]     (fused geometric combine)   or   gout[i,k,:]   (theta == NULL)

@@ -54,6 +54,15 @@ class TableGradDesc(ctypes.Structure):
         ("gtable0", c_vp), ("gtablek", c_vp), ("gdict", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("kernel", c_i32),
+        ("dict_pack", c_vp), ("dict_pack_K", c_i32),
+    ]
+
+
+class DictGradDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32), ("n_dict", c_i32),
+        ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp), ("gdict", c_vp),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -181,6 +190,10 @@ SIGNATURES = {
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
     "kpgnn_table_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 7),
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
+    "kpgnn_dict_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 4),
+    "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
+    "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),
     "kpgnn_combine_bwd": (ctypes.c_int, [ctypes.POINTER(CombineBwdDesc), c_vp]),
     "kpgnn_bn_fwd": (ctypes.c_int, [ctypes.POINTER(BnDesc), c_vp]),

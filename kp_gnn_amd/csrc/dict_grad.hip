@@ -1,0 +1,184 @@
+// Gradient of the peripheral dictionary under the fused geometric combine (gfx950).  Contract: include/kpgnn.h,
+// kpgnn_dict_grad.
+//
+//   gdict[u,:] = sum_k theta[k,:] * M[u,k,:],     M[u,k,:] = sum over nodes i with uid[i,k] == u of gh[i,:]
+//
+// (the dictionary row P[uid[i,k]] enters h_i = sum_k theta_k * (act(S_ik) + P_ik) linearly: KPGINplus.py:74-88 with the
+// peripheral features of models/GNNs.py:393-400 in their dictionary form).  Only gh [N,D] and the ids are read - not the
+// [N,K,D] gradient the edge-code tables need - so this is a 20 MB stream at the bench shape, against 158 MB when the
+// same sums ride along in kpgnn_table_grad's walk (where they cost 25-56 us of a launch).
+//
+// Wave w of a block owns hop w: it walks the block's contiguous run of nodes in order, keeps the sum of a run of equal
+// ids in registers (lane = two feature columns) and adds it to ITS accumulator row (u, w) in LDS with a plain
+// read-modify-write when the id changes.  No row is shared between waves, every sum has one fixed order (bitwise
+// reproducible), no atomics.  gh is staged through LDS once per block (all hops read the same rows) with the next
+// chunk's loads in flight.  At the end the block multiplies by theta, adds the hops in order and leaves [U,D] in its
+// slab row; a second launch adds the slabs in block order.
+#include "kpgnn_common.h"
+
+namespace kpgnn {
+namespace {
+
+constexpr int kWavesDG = 8;
+constexpr int kThreadsDG = kWave * kWavesDG;
+constexpr int kChunk = 32;                  // nodes per staged chunk of gh
+
+struct DgParams {
+    int N, K, D, U;
+    const int32_t* uid; int64_t uid_stride;
+    const float* theta;
+    const float* gh;
+    float* slab;                            // [gridDim.x][U][D]
+};
+
+// LDS (floats): acc [U*K][D] | ghs [2][kChunk][D]
+__global__ void __launch_bounds__(kThreadsDG)
+dict_grad_kernel(const DgParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int D = p.D, K = p.K, U = p.U;
+    const int c = lane * 2;
+    const bool col_ok = c < D;                        // D is even
+    const int cc = col_ok ? c : 0;
+    float* acc = lds;
+    float* ghs = lds + U * K * D;
+    for (int i = threadIdx.x; i < U * K * D; i += kThreadsDG) acc[i] = 0.f;
+    const int per = (p.N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(p.N, n0 + per);
+    const int chunk_floats = kChunk * D;              // multiple of 4 (D even, kChunk 32)
+    // chunk staging: thread t copies float4 t and t + 512 of the chunk (kChunk*D/4 <= 1024 float4: D <= 128)
+    float4 pre[2];
+    auto load_chunk = [&](int node0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = (q * kThreadsDG + threadIdx.x) * 4;
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < chunk_floats && node0 + i / D < n1)     // (D % 4 == 0 on this path: a float4 never straddles two rows)
+                pre[q] = *reinterpret_cast<const float4*>(p.gh + (int64_t)node0 * D + i);
+        }
+    };
+    auto load_uid = [&](int node0) -> int {          // lane l < kChunk: id of node node0 + l at this wave's hop
+        int v = -1;
+        if (w < K && lane < kChunk && node0 + lane < n1) v = p.uid[(int64_t)(node0 + lane) * p.uid_stride + w];
+        return v;
+    };
+    const bool vec_ok = (D % 4 == 0) && (((uintptr_t)p.gh & 15) == 0);
+    int cur = -1;
+    float ra = 0.f, rb = 0.f;                         // the running sum of the current id (two columns)
+    bool pending = false;                             // a finished run whose accumulator row is being read
+    float* pq = acc;
+    float2 pold = make_float2(0.f, 0.f), psum = make_float2(0.f, 0.f);
+    auto settle = [&]() {
+        if (pending) { if (col_ok) *reinterpret_cast<float2*>(pq) = make_float2(pold.x + psum.x, pold.y + psum.y); pending = false; }
+    };
+    auto leave = [&]() {
+        settle();
+        pq = acc + (cur * K + w) * D + cc;
+        pold = *reinterpret_cast<const float2*>(pq);
+        psum = make_float2(ra, rb);
+        pending = true;
+    };
+    int uidv = 0, nuid = 0;
+    if (n0 < n1) {
+        if (vec_ok) load_chunk(n0);
+        nuid = load_uid(n0);
+    }
+    int buf = 0;
+    for (int node0 = n0; node0 < n1; node0 += kChunk, buf ^= 1) {
+        float* gs = ghs + buf * chunk_floats;
+        uidv = nuid;
+        if (vec_ok) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = (q * kThreadsDG + threadIdx.x) * 4;
+                if (i < chunk_floats) *reinterpret_cast<float4*>(gs + i) = pre[q];
+            }
+            if (node0 + kChunk < n1) load_chunk(node0 + kChunk);
+        } else {
+            const int nn = min(kChunk, n1 - node0);
+            for (int i = threadIdx.x; i < nn * D; i += kThreadsDG) gs[i] = p.gh[(int64_t)node0 * D + i];
+        }
+        nuid = load_uid(node0 + kChunk);
+        __syncthreads();       // chunk staged; (two buffers: the previous chunk's readers are at most one barrier behind)
+        if (w < K) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < kChunk; j0 += 8) {
+                int u[8]; float2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    u[q] = __builtin_amdgcn_readlane(uidv, j0 + q);
+                    v[q] = *reinterpret_cast<const float2*>(gs + (j0 + q) * D + cc);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (u[q] >= 0) {
+                        if (u[q] != cur) {                         // wave-uniform
+                            if (cur >= 0) leave();
+                            cur = u[q];
+                            ra = rb = 0.f;
+                        }
+                        ra += v[q].x; rb += v[q].y;
+                    }
+                }
+            }
+        }
+    }
+    if (cur >= 0) leave();
+    settle();
+    __syncthreads();
+    // gdict_block[u, d] = sum_k theta[k, d] * acc[u, k, d], hops in order
+    for (int i = threadIdx.x; i < U * D; i += kThreadsDG) {
+        const int u = i / D, d = i - u * D;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(p.theta[k * D + d], acc[(u * K + k) * D + d], s);
+        p.slab[(int64_t)blockIdx.x * U * D + i] = s;
+    }
+}
+
+struct DgPlan { int grid; size_t lds, ws_bytes; };
+
+bool dg_plan(int N, int K, int D, int U, DgPlan* pl) {
+    if (N < 1 || K < 1 || K > kWavesDG || D < 2 || D > 2 * kWave || (D & 1) || U < 1) return false;
+    pl->lds = sizeof(float) * ((size_t)U * K * D + 2 * (size_t)kChunk * D);
+    if (pl->lds > 160 * 1024) return false;
+    int grid = device_facts().cu_count;
+    const int chunks = (N + kChunk - 1) / kChunk;
+    if (grid > chunks) grid = chunks;
+    pl->grid = grid < 1 ? 1 : grid;
+    pl->ws_bytes = sizeof(float) * (size_t)pl->grid * U * D;
+    return true;
+}
+
+}  // namespace
+}  // namespace kpgnn
+
+using namespace kpgnn;
+
+extern "C" size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t n_dict) {
+    DgPlan pl;
+    return dg_plan(N, K, D, n_dict, &pl) ? pl.ws_bytes : 0;
+}
+
+extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr, "dict_grad: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->D >= 1 && d->n_dict >= 1, "dict_grad: bad N=%d K=%d D=%d n_dict=%d", d->N, d->K,
+                  d->D, d->n_dict);
+    KPGNN_REQUIRE(d->gdict != nullptr, "dict_grad: NULL gdict");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->N == 0) { KPGNN_HIP_TRY(hipMemsetAsync(d->gdict, 0, sizeof(float) * (size_t)d->n_dict * d->D, s)); return KPGNN_OK; }
+    DgPlan pl;
+    if (!dg_plan(d->N, d->K, d->D, d->n_dict, &pl))
+        return fail(KPGNN_ELIMIT, "dict_grad: K=%d (<= 8), even D=%d (<= 128) and n_dict*K*D*4 + staging <= 160 KB of LDS needed "
+                    "(n_dict=%d); use kpgnn_table_grad's dictionary path", d->K, d->D, d->n_dict);
+    KPGNN_REQUIRE(d->uid && d->theta && d->gh && d->uid_stride >= d->K, "dict_grad: NULL uid/theta/gh or uid_stride < K");
+    KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "dict_grad: workspace too small (%zu < %zu)",
+                  (size_t)d->workspace_bytes, pl.ws_bytes);
+    DgParams p;
+    p.N = d->N; p.K = d->K; p.D = d->D; p.U = d->n_dict;
+    p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh; p.slab = (float*)d->workspace;
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)dict_grad_kernel, pl.lds));
+    hipLaunchKernelGGL(dict_grad_kernel, dim3(pl.grid), dim3(kThreadsDG), pl.lds, s, p);
+    KPGNN_LAUNCH_CHECK("dict_grad_kernel");
+    return slab_reduce(p.slab, pl.grid, (int64_t)p.U * p.D, d->gdict, (int64_t)p.U * p.D, nullptr, 0, nullptr, s);
+}

@@ -54,8 +54,17 @@ tgs_kernel(const TgsParams p) {
     const bool col_ok = c0 < Ds;
     using T = typename VT<VEC>::T;
     const int64_t tiles = (p.M + ROWS - 1) / ROWS;
+    // the first G indices of a row travel one trip ahead (the idx load -> shuffle -> LDS reads -> store chain of a trip
+    // otherwise starts with a global round trip: 344 us for the dense [N*K, 13] peripheral indices, latency-bound)
+    auto load_rows = [&](int64_t tile, int cb) -> int {
+        const int64_t m = tile * ROWS + sg;
+        return (tile < tiles && m < p.M && cb + sl < p.C) ? p.col_offset[cb + sl] + (int)p.idx[m * p.C + cb + sl] : 0;
+    };
+    int next_rows = load_rows(blockIdx.x, 0);
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t m = tile * ROWS + sg;
+        int myrow = next_rows;
+        next_rows = load_rows(tile + gridDim.x, 0);
         if (m >= p.M) continue;
         float acc[VEC];
         for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
@@ -64,8 +73,7 @@ tgs_kernel(const TgsParams p) {
             for (int q = 0; q < VEC; ++q) acc[q] = reinterpret_cast<const float*>(&b)[q];
         }
         for (int cb = 0; cb < p.C; cb += G) {
-            int myrow = 0;
-            if (cb + sl < p.C) myrow = p.col_offset[cb + sl] + (int)p.idx[m * p.C + cb + sl];
+            if (cb > 0) myrow = load_rows(tile, cb);
             const int cnt = min(G, p.C - cb);
             for (int t = 0; t < cnt; ++t) {
                 const int row = __shfl(myrow, sg_lane0 + t);
@@ -84,8 +92,11 @@ tgs_kernel(const TgsParams p) {
 
 // Backward: gtable[col_offset[c] + idx[m,c], :] += gout[m, :].  Block = NG groups of CW threads (CW = pow2 >= Ds); the
 // block's contiguous run of rows is cut into NG contiguous sub-runs, group g adds ITS rows in order into its private
-// accumulator table [R][CW] in LDS (thread = column: plain read-modify-write, no races); then the groups are added in
-// order and leave as slab row blockIdx.x.  slab: [gridDim.x][R][D].
+// accumulator table [R][CW] in LDS; then the groups are added in order and leave as slab row blockIdx.x.
+// slab: [gridDim.x][R][D].  Each accumulator cell belongs to ONE thread (thread = column), so there are no races and
+// the order of the additions is the program order of that thread.  They are issued as LDS atomics WITHOUT return value
+// (ds_add_f32) all the same: a plain `+=` is a load-add-store chain that waits for the LDS latency at every index, while
+// the fire-and-forget form keeps the LDS pipeline full and stays ordered per address within a wave.
 __global__ void __launch_bounds__(kBlock)
 tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [NG][R][CW]
@@ -97,24 +108,62 @@ tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
     const int64_t per_block = (p.M + gridDim.x - 1) / gridDim.x;
     const int64_t b0 = (int64_t)blockIdx.x * per_block;
     const int64_t b1 = b0 + per_block < p.M ? b0 + per_block : p.M;
-    if (grp < NG && col < Ds && b0 < b1) {
+    if (grp < NG && b0 < b1) {
         const int64_t per_grp = (b1 - b0 + NG - 1) / NG;
         const int64_t m0 = b0 + grp * per_grp;
         const int64_t m1 = m0 + per_grp < b1 ? m0 + per_grp : b1;
         float* acc = lds + (int64_t)grp * R * CW + col;
-        // four rows per trip: their loads are independent of the LDS read-modify-writes of the previous rows
-        for (int64_t m = m0; m < m1; m += 4) {
-            float g[4];
+        const bool col_ok = col < Ds;
+        if (CW % kWave == 0 && p.C <= kWave) {
+            // A group is made of whole waves: the indices of up to four rows arrive with ONE coalesced load per wave
+            // (lane j holds idx[m*C + j]) a trip ahead and are broadcast with v_readlane.  (One dependent global load per
+            // (row, component) in the loop cost 3.0 ms per launch on the dense [N*K, 13] peripheral indices.)
+            const int lane = threadIdx.x & (kWave - 1);
+            const int C = p.C, RT = min(4, kWave / C);
+            const int offv = lane < C ? p.col_offset[lane] : 0;
+            auto load_idx = [&](int64_t mm) -> int {
+                const int64_t n = (m1 - mm < RT ? m1 - mm : RT) * C;
+                return (mm < m1 && lane < n) ? (int)p.idx[mm * C + lane] : 0;
+            };
+            float g[4], ng[4];
+            auto load_g = [&](int64_t mm, float* o) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = m + u < m1 ? p.gout[(m + u) * p.gout_stride + col_base + col] : 0.f;
-            for (int c = 0; c < p.C; ++c) {
-                const int off = p.col_offset[c];
-                int row[4];
+                for (int u = 0; u < 4; ++u) o[u] = (u < RT && mm + u < m1 && col_ok) ? p.gout[(mm + u) * p.gout_stride + col_base + col] : 0.f;
+            };
+            int idxv = load_idx(m0);
+            load_g(m0, g);
+            for (int64_t m = m0; m < m1; m += RT) {
+                const int nidx = load_idx(m + RT);
+                load_g(m + RT, ng);
+                const int nrows = (int)(m1 - m < RT ? m1 - m : RT);
+                for (int c = 0; c < C; ++c) {
+                    const int off = __builtin_amdgcn_readlane(offv, c);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) row[u] = m + u < m1 ? off + (int)p.idx[(m + u) * p.C + c] : -1;
+                    for (int u = 0; u < 4; ++u)
+                        if (u < nrows) {
+                            const int row = off + __builtin_amdgcn_readlane(idxv, u * C + c);
+                            if (col_ok) atomicAdd(acc + row * CW, g[u]);   // ds_add_f32, no return: see the header
+                        }
+                }
+                idxv = nidx;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (row[u] >= 0) acc[row[u] * CW] += g[u];
+                for (int u = 0; u < 4; ++u) g[u] = ng[u];
+            }
+        } else if (col_ok) {
+            // four rows per trip: their loads are independent of the LDS adds of the previous rows
+            for (int64_t m = m0; m < m1; m += 4) {
+                float g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = m + u < m1 ? p.gout[(m + u) * p.gout_stride + col_base + col] : 0.f;
+                for (int c = 0; c < p.C; ++c) {
+                    const int off = p.col_offset[c];
+                    int row[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) row[u] = m + u < m1 ? off + (int)p.idx[(m + u) * p.C + c] : -1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (row[u] >= 0) atomicAdd(acc + row[u] * CW, g[u]);   // ds_add_f32, no return: see the header
+                }
             }
         }
     }

@@ -1,70 +1,95 @@
-// Table gradients without per-edge atomics (gfx950).  Contract: include/kpgnn.h, kpgnn_table_grad.
+// Table gradients without float atomics (gfx950).  Contract: include/kpgnn.h, kpgnn_table_grad.
 //
 //   gtable_t[c,:]  = sum over active pairs (i,k) of table t with code c of g[i,k,:]          (edge-code tables)
 //   gdict[u,:]     = sum over (i,k) with uid[i,k] == u of theta[k,:] * gh[i,:]               (peripheral dictionary)
 //
-// Why a separate kernel: LDS float atomics (ds_add_f32) per gathered edge row made the backward gather 5x
-// slower than the gather itself (622 us vs 120 us at N=47k, K=8, D=104: a handful of hot codes serialise),
-// and flushing per-block tables with global atomics made every block hammer the same few KB.
-// Here the accumulation is column-private: thread t owns feature column t of every table row, the tile's
-// pair list arrives sorted by (table, code), so a run of equal codes is summed in ONE register and written
-// to the thread's own LDS slot when the code changes.  g is streamed once, coalesced (a row = D floats),
-// the next tile's loads are in flight while the current tile is walked, and the pair list is wave-uniform
-// (scalar loads).  Per-block partial tables go to a workspace slab with plain stores; a second launch adds
-// the slabs in block order (deterministic; only the few per-tile LDS flushes of the walker groups race).
+// Why a separate kernel: LDS float atomics (ds_add_f32) per gathered edge row made the backward gather 5x slower
+// than the gather itself (a handful of hot codes serialise), and per-entry LDS atomics on the ~25 hot dictionary rows
+// alone cost 56 us of a 122 us launch (round 2: ~45 cycles of the CU's LDS pipe per wave-wide float atomic).
+//
+// Design: a block owns a tile of nodes_per_tile nodes; g of the tile ([NT*K][D], contiguous) is copied to LDS with 16-B
+// loads that were requested one tile ahead.  The tile's entries arrive SORTED by accumulator row - the edge list by
+// (table, code) from kpgnn_csr_build, the dictionary list by uid from kpgnn_dict_tile_pack - and each of the eight
+// waves walks a contiguous chunk of each list: lane = two feature columns (one for odd D), the entries are wave-uniform
+// (one coalesced load, then v_readlane), a run of equal rows is summed in registers and leaves once when the row
+// changes.  Rows whose run lies inside a chunk belong to that wave alone in this tile: the run is added to the block's
+// LDS accumulator table without any race.  Only the first run of a chunk can continue a row of the previous wave; it
+// is parked in a per-wave LDS slot instead, and after the tile's barrier the wave that OWNS the row (the first one that
+// holds it) adds the slots of its followers in wave order.  Every sum therefore has one fixed order: results are
+// bitwise reproducible (the replay == eager test relies on it), and no float atomic is contended.
+// Per-block tables go to a workspace slab with plain stores; a second launch adds the slabs in block order.
 #include "kpgnn_common.h"
 
 namespace kpgnn {
 namespace {
 
-constexpr int kCols = 128;    // feature columns per block (one walker group = kCols threads = 2 waves)
-constexpr int kGroups = 4;    // walker groups per block: each walks a quarter of the tile's pair list
-constexpr int kThreadsTG = kCols * kGroups;
-constexpr int kMaxRows = 64;  // NT*K: at most 8 nodes x 8 hops per tile
+constexpr int kWavesTG = 8;                 // walker waves per block
+constexpr int kThreadsTG = kWave * kWavesTG;
+constexpr int kMaxRows = 64;                // NT*K: at most 8 nodes x 8 hops per tile
+constexpr int kSlotRows = 2 * kWavesTG;     // first-run slots: [list][wave]
 
 struct TgParams {
-    int N, K, D, NT, n0, nk, U, dict_src;
+    int N, K, D, NT, n0, nk, U, dict_src, KD;
     const int32_t* tptr;
     const uint32_t* tpack;
     const float* g;
-    // peripheral dictionary (optional): gdict[uid[i*uid_stride + k]] += theta[k,:] * gh[i,:]
+    // peripheral dictionary (optional): gdict[uid[i*uid_stride + k]] += theta[k,:] * gh[i,:]   (dict_src 1; 2: g rows)
     const int32_t* uid; int64_t uid_stride;
+    const uint32_t* dpack;   // [tiles][64] uid<<8 | node<<3 | hop sorted by uid (0xFFFFFFFF = none)
     const float* theta;
     const float* gh;
-    float* slab;          // [gridDim.x][n0 + nk + U][D]
+    float* slab;             // [gridDim.x][n0 + nk + U][D]
 };
 
-// g must be contiguous [N,K,D]: a tile of NT nodes is then one contiguous run of NT*K*D floats, copied to
-// LDS as is (16-B loads when D % 4 == 0); thread t reads column d of row r at tile[r*D + d] (bank = d).
-// The kGroups walker groups share the tile and the accumulator table; a group keeps the running sum of ITS
-// current code in a register and flushes it with an LDS atomic (a code can straddle two groups' chunks; the
-// flushes are a handful per tile, so the atomics cost nothing - unlike one atomic per edge).
-template <bool VEC4>
-__global__ void __launch_bounds__(kThreadsTG)
-table_grad_kernel(const TgParams p) {
+template <int CPL> struct Cols;
+template <> struct Cols<1> {
+    float a;
+    __device__ __forceinline__ void zero() { a = 0.f; }
+    __device__ __forceinline__ void load(const float* q) { a = *q; }
+    __device__ __forceinline__ void store(float* q) const { *q = a; }
+    __device__ __forceinline__ void fma(float m, const Cols& v) { a = fmaf(m, v.a, a); }
+    __device__ __forceinline__ void fmul(const Cols& x, const Cols& y) { a = fmaf(x.a, y.a, a); }
+    __device__ __forceinline__ void add(const Cols& v) { a += v.a; }
+};
+template <> struct Cols<2> {
+    float a, b;
+    __device__ __forceinline__ void zero() { a = b = 0.f; }
+    __device__ __forceinline__ void load(const float* q) { const float2 v = *reinterpret_cast<const float2*>(q); a = v.x; b = v.y; }
+    __device__ __forceinline__ void store(float* q) const { *reinterpret_cast<float2*>(q) = make_float2(a, b); }
+    __device__ __forceinline__ void fma(float m, const Cols& v) { a = fmaf(m, v.a, a); b = fmaf(m, v.b, b); }
+    __device__ __forceinline__ void fmul(const Cols& x, const Cols& y) { a = fmaf(x.a, y.a, a); b = fmaf(x.b, y.b, b); }
+    __device__ __forceinline__ void add(const Cols& v) { a += v.a; b += v.b; }
+};
+
+// LDS (floats): tile [NT*K*D] | acc [(R + kSlotRows)][AS] | ghs [NT][AS] | ths [8][AS] | meta [2*kWavesTG] (uint32)
+// AS = the block's column count (gridDim.y == 1: D).  acc rows R.. are the first-run slots.
+template <int CPL, bool VEC4>
+__global__ void __launch_bounds__(kThreadsTG, 4)   // (HIP: waves per SIMD) two blocks per CU: 128 VGPRs
+table_grad_kernel(const TgParams p, int AS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kCols);   // wave-uniform: keeps the walk in SALU control flow
-    const int t = threadIdx.x % kCols;
-    const int lane = t & 63;
-    const int d = blockIdx.y * kCols + t;
-    const bool col_ok = d < p.D;
-    const int dc = col_ok ? d : 0;                   // clamped column for address arithmetic
-    const int D = p.D;
-    const int R = p.n0 + p.nk + p.U;                 // table rows
-    const int tile_floats = p.NT * p.K * D;
-    float* tile = lds;                               // [NT*K][D]
-    float* acc = lds + ((tile_floats + 3) & ~3);     // [R][kCols], column-private
-    float* ghs = acc + R * kCols;                    // [8][kCols]
-    for (int r = grp; r < R; r += kGroups) acc[r * kCols + t] = 0.f;
+    using CV = Cols<CPL>;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform: keeps the walk in SALU control flow
+    const int lane = threadIdx.x & (kWave - 1);
+    const int cb = blockIdx.y * kWave * CPL;          // first column of this block
+    const int c = lane * CPL;                         // this lane's column(s) inside the block
+    const bool col_ok = cb + c < p.D;                 // (D % CPL == 0: both columns or none)
+    const int cc = col_ok ? c : 0;
+    const int D = p.D, K = p.K;
+    const int R = p.n0 + p.nk + p.U;
+    const int tile_floats = p.NT * K * D;
+    float* tile = lds;
+    float* acc = lds + ((tile_floats + 3) & ~3);
+    float* ghs = acc + (R + kSlotRows) * AS;
+    float* ths = ghs + 8 * AS;
+    uint32_t* meta = reinterpret_cast<uint32_t*>(ths + 8 * AS);
+    for (int i = threadIdx.x; i < (R + kSlotRows) * AS; i += kThreadsTG) acc[i] = 0.f;
+    if (p.dict_src == 1)
+        for (int i = threadIdx.x; i < 8 * AS; i += kThreadsTG) {
+            const int k = i / AS, q = i - k * AS;
+            ths[i] = (k < K && cb + q < D) ? p.theta[k * D + cb + q] : 0.f;
+        }
     const int64_t num_tiles = ((int64_t)p.N + p.NT - 1) / p.NT;
-    const int64_t total = (int64_t)p.N * p.K * D;
-    int cur = -1;       // current accumulator row (table offset + code), -1 = none
-    float run = 0.f;
-    int ucur = -1;      // current dictionary row
-    float urun = 0.f;
-    float th[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) th[k] = (p.dict_src == 1 && k < p.K && col_ok) ? p.theta[k * D + d] : 0.f;
+    const int64_t total = (int64_t)p.N * K * D;
     constexpr int kPref = 4;
     float4 pref[kPref];
     if (VEC4) {
@@ -76,39 +101,28 @@ table_grad_kernel(const TgParams p) {
                 pref[q] = *reinterpret_cast<const float4*>(p.g + i);
         }
     }
-    // Per-tile metadata travels two tiles ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the
-    // window that arrived an iteration ago, the first 64 entries / dictionary ids / gh values of tile i+1, so that no
-    // dependent global round trip (tile_ptr -> tile_pack) sits in front of a walk.  (Worth ~3 us per launch only: the
-    // walk itself, not its operands' latency, is the critical path.)
-    // (Measured alternatives, k = 8, D = 104: hop-major entry order 90 us, chunks cut at table-row boundaries with plain
-    //  read-modify-write flushes 75 us, this version 62 us - DESIGN.md section 5.)
-    struct TileMeta { int beg, end; uint32_t nxt; int uid; float gh[2]; };
-    static_assert(kGroups * 2 >= 8, "two gh values per thread cover a tile of up to 8 nodes");
-    // window of tile t2: lane 0 fetches its begin, lane 1 its end (kept as a per-lane value on purpose: a wave-uniform
-    // load is waited for where it is issued, to move it to scalar registers)
-    auto load_range = [&](int64_t t2) -> int {
+    // Per-tile metadata travels ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the window
+    // that arrived an iteration ago, this wave's entries / dictionary entries / gh row of tile i+1, so that no dependent
+    // global round trip (tile_ptr -> tile_pack) sits in front of a walk.
+    struct TileMeta { int beg, end; uint32_t nxt, dnx; CV gh; };
+    auto load_range = [&](int64_t t2) -> int {       // lane 0: begin of the tile's window, lane 1: its end
         int v = 0;
         if (p.tptr && t2 < num_tiles && lane < 2) v = p.tptr[t2 + lane];
         return v;
     };
     auto load_meta = [&](int64_t t2, int rb, int re, TileMeta& m) {
-        // this group's contiguous chunk of the sorted entry list (multiple of 8 entries except the tail)
-        const int per = ((re - rb + kGroups - 1) / kGroups + 7) & ~7;
-        m.beg = min(re, rb + grp * per);
+        // this wave's contiguous chunk of the sorted entry list
+        const int per = (re - rb + kWavesTG - 1) / kWavesTG;
+        m.beg = min(re, rb + w * per);
         m.end = min(re, m.beg + per);
         m.nxt = (m.beg + lane < m.end) ? p.tpack[m.beg + lane] : 0xFFFFFFFFu;   // hop 63 == skip
-        m.uid = -1;                                  // lane l: dictionary row of tile row l (NT*K <= 64)
-        if (p.U > 0 && lane < p.NT * p.K && t2 < num_tiles) {
-            const int n = lane / p.K;
-            const int64_t node = t2 * p.NT + n;
-            if (node < p.N) m.uid = p.uid[node * p.uid_stride + (lane - n * p.K)];
+        m.dnx = 0xFFFFFFFFu;                          // lanes 0..7: this wave's eight dictionary entries of the tile
+        if (p.U > 0 && t2 < num_tiles && lane < 8) {
+            m.dnx = p.dpack[t2 * 64 + w * 8 + lane];
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                // gh rows of the tile's nodes, column t
-            const int n = grp + q * kGroups;
-            const int64_t node = t2 * p.NT + n;
-            m.gh[q] = (p.dict_src == 1 && n < p.NT && t2 < num_tiles && node < p.N && col_ok) ? p.gh[node * D + d] : 0.f;
-        }
+        m.gh.zero();                                  // wave w stages the gh row of the tile's node w
+        const int64_t node = t2 * p.NT + w;
+        if (p.dict_src == 1 && w < p.NT && t2 < num_tiles && node < p.N && col_ok) m.gh.load(p.gh + node * D + cb + c);
     };
     TileMeta cm;
     int rng1;
@@ -117,21 +131,87 @@ table_grad_kernel(const TgParams p) {
         load_meta(blockIdx.x, __builtin_amdgcn_readlane(rng0, 0), __builtin_amdgcn_readlane(rng0, 1), cm);
         rng1 = load_range((int64_t)blockIdx.x + gridDim.x);
     }
+    // what a finished walk leaves for the boundary pass: the last run of each list (registers) and the packed chunk
+    // description  nonempty | whole << 1 | first_row << 2 | last_row << 14
+    CV lastE, lastD;
+    uint32_t myE = 0, myD = 0;
+    lastE.zero(); lastD.zero();
+    // The boundary pass of the PREVIOUS tile: runs between that tile's closing barrier and this tile's walk.
+    auto boundary = [&](int list, uint32_t mine, const CV& last, uint32_t metav) {
+        if (!(mine & 1)) return;
+        const bool whole = mine & 2;
+        const int first_row = (mine >> 2) & 0xFFF, last_row = (mine >> 14) & 0xFFF;
+        bool owned = false;                           // does an earlier wave hold my first row?
+        for (int w2 = w - 1; w2 >= 0; --w2) {
+            const uint32_t m = __builtin_amdgcn_readlane(metav, list * kWavesTG + w2);
+            if (!(m & 1)) continue;
+            owned = (int)((m >> 14) & 0xFFF) == first_row;
+            break;
+        }
+        // the row whose followers I add up: my last run, or my only run when nobody before me holds it
+        const bool has_tail = !whole || !owned;
+        const int tail_row = whole ? first_row : last_row;
+        uint32_t take = 0;                            // later waves whose parked first run continues that row
+        if (has_tail)
+            for (int w2 = w + 1; w2 < kWavesTG; ++w2) {
+                const uint32_t m = __builtin_amdgcn_readlane(metav, list * kWavesTG + w2);
+                if (!(m & 1)) continue;
+                if ((int)((m >> 2) & 0xFFF) != tail_row) break;
+                take |= 1u << w2;
+                if (!(m & 2)) break;
+            }
+        // all LDS reads first (independent), then the sums in wave order, then the writes: the rows and slots touched here
+        // are this wave's alone until the next barrier
+        float* slots = acc + (R + list * kWavesTG) * AS + cc;
+        CV own, afirst, atail, z;
+        z.zero(); own.zero();
+        if (!owned) own.load(slots + w * AS);
+        const bool first_alone = !owned && !whole;    // my first run ended inside my chunk: nobody else holds its row
+        if (first_alone) afirst.load(acc + first_row * AS + cc);
+        if (has_tail) atail.load(acc + tail_row * AS + cc);
+        CV tot = last;
+        if (whole) tot = own;
+#pragma unroll
+        for (int j0 = 1; j0 < kWavesTG; j0 += 4) {    // followers in groups of four (register budget)
+            if ((take >> (w + j0)) == 0) break;
+            CV fv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w + j0 + j < kWavesTG && ((take >> (w + j0 + j)) & 1)) fv[j].load(slots + (w + j0 + j) * AS);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w + j0 + j < kWavesTG && ((take >> (w + j0 + j)) & 1)) {
+                    tot.add(fv[j]);
+                    if (col_ok) z.store(slots + (w + j0 + j) * AS);
+                }
+        }
+        if (!owned && col_ok) z.store(slots + w * AS);
+        if (first_alone) { afirst.add(own); if (col_ok) afirst.store(acc + first_row * AS + cc); }
+        if (has_tail) {
+            atail.add(tot);
+            if (col_ok) atail.store(acc + tail_row * AS + cc);
+        }
+    };
+    bool have_prev = false;
     for (int64_t tl = blockIdx.x; tl < num_tiles; tl += gridDim.x) {
         // Consume this tile's metadata NOW (requested an iteration ago): the wait then sits in front of the loads issued
-        // below for the next tile; a wait placed inside the walk would be a vmcnt(0) that also waits for the g rows just
-        // requested for the next tile.
-        uint32_t mine = cm.nxt;
-        int myuid = cm.uid;                           // lane l: dictionary row of tile row l
-        float gh0 = cm.gh[0], gh1 = cm.gh[1];
-        asm volatile("" : "+v"(mine), "+v"(myuid), "+v"(gh0), "+v"(gh1));
-        TileMeta nm;                                  // next tile (its window arrived with the loads above) and the one after
+        // below for the next tile.
+        uint32_t mine = cm.nxt, dmine = cm.dnx;
+        CV ghv = cm.gh;
+        asm volatile("" : "+v"(mine), "+v"(dmine));
+        TileMeta nm;
         load_meta(tl + gridDim.x, __builtin_amdgcn_readlane(rng1, 0), __builtin_amdgcn_readlane(rng1, 1), nm);
         rng1 = load_range(tl + 2 * (int64_t)gridDim.x);
-        int beg = cm.beg, end = cm.end;
+        const int beg = cm.beg, end = cm.end;
         const int64_t base = tl * tile_floats;
         const int nfl = (int)min((int64_t)tile_floats, total - base);
-        __syncthreads();                             // previous tile fully walked
+        __syncthreads();                             // previous tile fully walked, its chunk descriptions are in LDS
+        if (have_prev) {
+            const uint32_t metav = lane < 2 * kWavesTG ? meta[lane] : 0u;
+            boundary(0, myE, lastE, metav);
+            boundary(1, myD, lastD, metav);
+        }
+        have_prev = true;
         if (VEC4) {
             // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
@@ -151,83 +231,180 @@ table_grad_kernel(const TgParams p) {
         } else {
             for (int i = threadIdx.x; i < nfl; i += kThreadsTG) tile[i] = p.g[base + i];
         }
-        if (p.dict_src == 1) {
-            if (grp < p.NT) ghs[grp * kCols + t] = gh0;
-            if (grp + kGroups < p.NT) ghs[(grp + kGroups) * kCols + t] = gh1;
-        }
+        if (p.dict_src == 1 && w < p.NT && col_ok) ghv.store(ghs + w * AS + cc);
         __syncthreads();
-        // ---- walk the (table,code)-sorted pair list of this tile.  Each wave fetches 64 entries with ONE
-        //      coalesced load (lane l holds entry l) and broadcasts them with v_readlane (SGPR, no LDS, no
-        //      scalar-cache misses); the LDS tile reads of 8 entries are issued back to back before the
-        //      (sequential, register-only) run accumulation.  The next chunk is fetched while this one is walked.
-        // every lane decodes ITS entry once (VALU, 64 entries per instruction); the per-entry scalar work is then three
-        // v_readlane, one compare and the fma
-        int vmul, voff, vrow;
-        auto decode = [&](uint32_t w) {
-            const int vhop = w & 0x3F;
-            const bool vok = vhop < p.K;
-            vmul = __float_as_int((float)(((w >> 6) & 0x3F) + 1));        // multiplicity of the merged entry
-            voff = vok ? ((int)((w >> 12) & 7) * p.K + vhop) * D : 0;
-            const int vcc = (int)(w >> 15);                                // table<<16 | code
-            vrow = vok ? ((vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc) : -1;
-        };
-        decode(mine);
-        for (int b0 = beg; b0 < end; b0 += 64) {
-            const int cnt = min(64, end - b0);
-            for (int e0 = 0; e0 < cnt; e0 += 8) {
-                int off[8], row[8]; float val[8], mul[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    off[u] = __builtin_amdgcn_readlane(voff, e0 + u);
-                    row[u] = __builtin_amdgcn_readlane(vrow, e0 + u);
-                    mul[u] = __int_as_float(__builtin_amdgcn_readlane(vmul, e0 + u));
+        // ---- walk this wave's chunk of the (table,code)-sorted pair list.  Every lane decodes ITS entry once (VALU, 64
+        //      entries per instruction); per entry the wave then pays three v_readlane, one LDS read, a compare and the fma.
+        //      The LDS reads of 8 entries are issued back to back before the (sequential, register-only) run accumulation.
+        {
+            int vmul, voff, vrow;
+            auto decode = [&](uint32_t e) {
+                const int vhop = e & 0x3F;
+                const bool vok = vhop < K;
+                vmul = __float_as_int((float)(((e >> 6) & 0x3F) + 1));       // multiplicity of the merged entry
+                voff = vok ? ((int)((e >> 12) & 7) * K + vhop) * D + cb : 0;
+                const int vcc = (int)(e >> 15);                               // table<<16 | code
+                vrow = vok ? ((vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc) : -1;
+            };
+            decode(mine);
+            int cur = -1, first_row = 0;
+            bool first = true;
+            CV run;
+            run.zero();
+            // A finished run is added to its row with a plain read-modify-write (the row is this wave's alone until the
+            // next barrier).  The read is issued when the run ends and the add + write when the NEXT run ends, so that the
+            // LDS latency hides behind the next run instead of stalling the walk.  The chunk's first run is parked in this
+            // wave's slot with a plain store (the slot's reader left it zero).  (ds_add_f32 is no alternative: ~150 cycles
+            // of the CU's LDS pipe per wave-wide float atomic, contended or not; batching the read-modify-writes of a
+            // group of entries costs more registers than the kernel has at two blocks per CU - DESIGN.md.)
+            bool pending = false;
+            float* pq = acc;
+            CV pold, psum;
+            auto settle = [&]() {
+                if (pending) { pold.add(psum); if (col_ok) pold.store(pq); pending = false; }
+            };
+            auto leave = [&]() {                     // the finished run of row `cur`
+                if (first) {
+                    first_row = cur; first = false;
+                    if (col_ok) run.store(acc + (R + w) * AS + cc);
+                } else {
+                    settle();
+                    pq = acc + cur * AS + cc;
+                    pold.load(pq);
+                    psum = run;
+                    pending = true;
                 }
+            };
+            for (int b0 = beg; b0 < end; b0 += 64) {
+                const int cnt = min(64, end - b0);
+                for (int e0 = 0; e0 < cnt; e0 += 8) {
+                    int off[8], row[8]; float mul[8]; CV val[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) val[u] = tile[off[u] + dc];
+                    for (int u = 0; u < 8; ++u) {
+                        off[u] = __builtin_amdgcn_readlane(voff, e0 + u);
+                        row[u] = __builtin_amdgcn_readlane(vrow, e0 + u);
+                        mul[u] = __int_as_float(__builtin_amdgcn_readlane(vmul, e0 + u));
+                    }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (row[u] >= 0) {
-                        if (row[u] != cur) {                               // wave-uniform
-                            if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
-                            cur = row[u];
-                            run = 0.f;
+                    for (int u = 0; u < 8; ++u) val[u].load(tile + off[u] + cc);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (row[u] >= 0) {
+                            if (row[u] != cur) {                           // wave-uniform
+                                if (cur >= 0) leave();
+                                cur = row[u];
+                                run.zero();
+                            }
+                            run.fma(mul[u], val[u]);
                         }
-                        run = fmaf(mul[u], val[u], run);
                     }
                 }
+                if (b0 + 64 < end)                   // (rare: > 64 entries in a wave's chunk)
+                    decode((b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu);
             }
-            if (b0 + 64 < end)                       // (rare: > 64 entries in a group's chunk; fetched and decoded here so
-                decode((b0 + 64 + lane < end) ? p.tpack[b0 + 64 + lane] : 0xFFFFFFFFu);   //  that the loop carries no pending load)
+            myE = 0;
+            if (cur >= 0) {
+                const bool whole = first;
+                if (whole) leave();                  // a single run: it is the chunk's first run -> parked
+                settle();
+                myE = 1u | (whole ? 2u : 0u) | ((uint32_t)first_row << 2) | ((uint32_t)cur << 14);
+                lastE = run;
+            }
         }
-        // ---- peripheral dictionary: rows in natural order, equal uids (the common case) stay in a register;
-        //      theta / gh sit in registers, the (wave-uniform) uids of a node are fetched together
+        // ---- peripheral dictionary: this wave's eight entries of the tile's uid-sorted list
         if (p.U > 0) {
-            const int64_t node0 = tl * p.NT;
-            for (int n = grp; n < p.NT && node0 + n < p.N; n += kGroups) {
-                const float ghv = ghs[n * kCols + t];
+            const bool dok = dmine != 0xFFFFFFFFu && (int)(dmine & 7) < K;
+            const int dn = (dmine >> 3) & 7, dk = dmine & 7;
+            const int drow = dok ? p.n0 + p.nk + (int)(dmine >> 8) : -1;
+            const int doa = p.dict_src == 1 ? dn * AS : (dn * K + dk) * D + cb;   // gh row / g row of the tile
+            const int dob = dk * AS;                                              // theta row
+            int cur = -1, first_row = 0;
+            bool first = true;
+            CV run;
+            run.zero();
+            bool pending = false;
+            float* pq = acc;
+            CV pold, psum;
+            auto settle = [&]() {
+                if (pending) { pold.add(psum); if (col_ok) pold.store(pq); pending = false; }
+            };
+            auto leave = [&]() {
+                if (first) {
+                    first_row = cur; first = false;
+                    if (col_ok) run.store(acc + (R + kWavesTG + w) * AS + cc);
+                } else {
+                    settle();
+                    pq = acc + cur * AS + cc;
+                    pold.load(pq);
+                    psum = run;
+                    pending = true;
+                }
+            };
+            int row[8]; CV va[8], vb[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k >= p.K) break;
-                    const int u = __builtin_amdgcn_readlane(myuid, n * p.K + k);   // wave-uniform
-                    if (u != ucur) {
-                        if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
-                        ucur = u;
-                        urun = 0.f;
-                    }
-                    if (p.dict_src == 1) urun = fmaf(th[k], ghv, urun);
-                    else urun += tile[(n * p.K + k) * D + dc];
+            for (int u = 0; u < 8; ++u) {
+                row[u] = __builtin_amdgcn_readlane(drow, u);
+                const int oa = __builtin_amdgcn_readlane(doa, u);
+                if (p.dict_src == 1) {
+                    va[u].load(ghs + oa + cc);
+                    vb[u].load(ths + __builtin_amdgcn_readlane(dob, u) + cc);
+                } else {
+                    va[u].load(tile + oa + cc);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (row[u] >= 0) {
+                    if (row[u] != cur) {
+                        if (cur >= 0) leave();
+                        cur = row[u];
+                        run.zero();
+                    }
+                    if (p.dict_src == 1) run.fmul(va[u], vb[u]);
+                    else run.add(va[u]);
+                }
+            }
+            myD = 0;
+            if (cur >= 0) {
+                const bool whole = first;
+                if (whole) leave();
+                settle();
+                myD = 1u | (whole ? 2u : 0u) | ((uint32_t)first_row << 2) | ((uint32_t)cur << 14);
+                lastD = run;
+            }
         }
+        if (lane == 0) { meta[w] = myE; meta[kWavesTG + w] = myD; }
         cm = nm;
     }
-    if (cur >= 0) atomicAdd(&acc[cur * kCols + t], run);
-    if (ucur >= 0) atomicAdd(&acc[(p.n0 + p.nk + ucur) * kCols + t], urun);
     __syncthreads();
-    if (col_ok) {
-        float* out = p.slab + (int64_t)blockIdx.x * R * D + d;
-        for (int r = grp; r < R; r += kGroups) out[(int64_t)r * D] = acc[r * kCols + t];
+    if (have_prev) {
+        const uint32_t metav = lane < 2 * kWavesTG ? meta[lane] : 0u;
+        boundary(0, myE, lastE, metav);
+        boundary(1, myD, lastD, metav);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * AS; i += kThreadsTG) {
+        const int r = i / AS, q = i - r * AS;
+        if (cb + q < D) p.slab[((int64_t)blockIdx.x * R + r) * D + cb + q] = acc[i];
+    }
+}
+
+// Dictionary entries of every tile, sorted by dictionary row: pack[tile*64 + j] = uid << 8 | node_in_tile << 3 | hop.
+// One wave per tile; 64 keys are ranked by counting (a one-off per batch: the ids are data, not parameters).
+__global__ void __launch_bounds__(kWave)
+dict_tile_pack_kernel(const int32_t* __restrict__ uid, int64_t uid_stride, int N, int K, int NT, uint32_t* __restrict__ pack) {
+    const int lane = threadIdx.x;
+    const int64_t tl = blockIdx.x;
+    const int n = lane / K, k = lane - n * K;
+    const int64_t node = tl * NT + n;
+    uint32_t key = 0xFFFFFFFFu;
+    if (n < NT && node < N) key = ((uint32_t)uid[node * uid_stride + k] << 8) | (uint32_t)(n << 3 | k);
+    int rank = 0;
+    for (int j = 0; j < kWave; ++j) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+        rank += (o < key || (o == key && j < lane)) ? 1 : 0;
+    }
+    pack[tl * 64 + rank] = key;
 }
 
 // out[e] = sum_b slab[b][e]   (fixed order: deterministic).  16 outputs x 64 slices of the slab range per WG: each
@@ -276,13 +453,18 @@ int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_
 
 namespace {
 
-struct Plan { int grid_x, grid_y; size_t lds, ws_bytes; int R; };
+struct Plan { int grid_x, grid_y, cpl, AS; size_t lds, ws_bytes; int R; };
 
 int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     if (NT * K > kMaxRows || K > 8 || NT > 8)
         return fail(KPGNN_ELIMIT, "table_grad: nodes_per_tile=%d x K=%d exceeds the %d-row (8x8) register tile", NT, K, kMaxRows);
     pl->R = n0 + nk + U;
-    pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)kCols * (pl->R + 8));
+    if (pl->R + kSlotRows > 4095) return fail(KPGNN_ELIMIT, "table_grad: %d table rows exceed the 12-bit row id", pl->R);
+    pl->cpl = (D % 2 == 0) ? 2 : 1;
+    const int cols = kWave * pl->cpl;
+    pl->grid_y = (D + cols - 1) / cols;
+    pl->AS = pl->grid_y == 1 ? D : cols;
+    pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)pl->AS * (pl->R + kSlotRows + 16)) + 2 * kWavesTG * 4;
     if (pl->lds > 160 * 1024)
         return fail(KPGNN_ELIMIT, "table_grad: %zu B of LDS needed (tile %dx%d rows + %d table rows)", pl->lds, NT, K, pl->R);
     const int64_t num_tiles = ((int64_t)N + NT - 1) / NT;
@@ -292,8 +474,15 @@ int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     if (gx > num_tiles) gx = num_tiles;
     if (gx < 1) gx = 1;
     pl->grid_x = (int)gx;
-    pl->grid_y = (D + kCols - 1) / kCols;
     pl->ws_bytes = sizeof(float) * (size_t)gx * pl->R * D;
+    return KPGNN_OK;
+}
+
+template <int CPL, bool VEC4>
+int launch_walk(const TgParams& p, const Plan& pl, hipStream_t s) {
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4>, pl.lds));
+    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
+    KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return KPGNN_OK;
 }
 
@@ -311,6 +500,19 @@ extern "C" size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t
     return pl.ws_bytes > mfma ? pl.ws_bytes : mfma;  // 0 means "neither kernel fits": the caller takes its atomic fallback
 }
 
+extern "C" int kpgnn_dict_tile_pack(const int32_t* uid, int64_t uid_stride, int32_t N, int32_t K, int32_t nodes_per_tile,
+                                    uint32_t* pack, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(N >= 0 && K >= 1 && K <= 8 && nodes_per_tile >= 1 && nodes_per_tile <= 8 && nodes_per_tile * K <= kMaxRows,
+                  "dict_tile_pack: bad N=%d K=%d nodes_per_tile=%d (tiles of at most 8 nodes x 8 hops)", N, K, nodes_per_tile);
+    if (N == 0) return KPGNN_OK;
+    KPGNN_REQUIRE(uid && pack && uid_stride >= K, "dict_tile_pack: NULL uid/pack or uid_stride < K");
+    const int64_t tiles = ((int64_t)N + nodes_per_tile - 1) / nodes_per_tile;
+    hipLaunchKernelGGL(dict_tile_pack_kernel, dim3((unsigned)tiles), dim3(kWave), 0, (hipStream_t)stream, uid, uid_stride,
+                       N, K, nodes_per_tile, pack);
+    KPGNN_LAUNCH_CHECK("dict_tile_pack_kernel");
+    return KPGNN_OK;
+}
+
 extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "table_grad: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->K <= 4096 && d->D >= 1 && d->nodes_per_tile >= 1 && d->nodes_per_tile <= 8,
@@ -323,15 +525,20 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->n_dict >= 0 && (d->n_dict == 0 || (d->uid && d->gdict && d->uid_stride >= d->K &&
                   (d->dict_src == 2 || (d->dict_src == 1 && d->theta && d->gh)))),
                   "table_grad: dictionary gradient needs uid/gdict and (theta, gh) or dict_src 2");
+    KPGNN_REQUIRE(d->n_dict == 0 || !d->dict_pack || (d->dict_pack_K >= d->K && d->dict_pack_K <= 8),
+                  "table_grad: dict_pack was built for %d hops, g has %d", d->dict_pack_K, d->K);
     KPGNN_REQUIRE(edges || d->n_dict > 0, "table_grad: nothing to do");
     hipStream_t s = (hipStream_t)stream;
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
         // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
-        // dictionary rows) at D = 13.  Wide rows stay on the register walk (D = 104: 78 vs 121 us; the 16x16x4 product
-        // is matrix-core bound there).  d->kernel = 1 / 2 forces one of them (the parity tests compare the two).
+        // dictionary rows) at D = 13.  Wide rows stay on the register walk (the 16x16x4 product is matrix-core bound
+        // there).  d->kernel = 1 / 2 forces one of them (the parity tests compare the two).
         const int force = d->kernel;
-        const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows;
+        // (the walk adds finished runs with plain read-modify-writes: it needs BOTH lists sorted by row)
+        const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows && (d->n_dict == 0 || d->dict_pack);
+        KPGNN_REQUIRE(force != 1 || walk_fits, "table_grad: the walk kernel needs K <= 8, tiles of <= 64 (node, hop) rows and, "
+                      "with a dictionary, the uid-sorted list of kpgnn_dict_tile_pack");
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
@@ -344,6 +551,9 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     p.U = d->n_dict; p.dict_src = d->dict_src;
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh;
+    // the sorted dictionary list addresses hops with the stride it was built for; it only applies when that is g's K
+    // (a list built for all K hops serves every layer: entries of hops >= d->K are skipped)
+    p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.KD = d->dict_pack_K;
     Plan pl;
     int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl);
     if (rc != KPGNN_OK) return rc;
@@ -352,13 +562,9 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     p.slab = (float*)d->workspace;
     // the tile copy is flat: 16-B loads only need every node's K*D floats to be a multiple of 4
     const bool vec4 = (((int64_t)p.K * p.D) % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
-    if (pl.lds > 64 * 1024) {
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<true>, pl.lds));
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<false>, pl.lds));
-    }
-    if (vec4) hipLaunchKernelGGL((table_grad_kernel<true>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
-    else hipLaunchKernelGGL((table_grad_kernel<false>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p);
-    KPGNN_LAUNCH_CHECK("table_grad_kernel");
+    if (pl.cpl == 2) rc = vec4 ? launch_walk<2, true>(p, pl, s) : launch_walk<2, false>(p, pl, s);
+    else rc = vec4 ? launch_walk<1, true>(p, pl, s) : launch_walk<1, false>(p, pl, s);
+    if (rc != KPGNN_OK) return rc;
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
                        (int64_t)p.nk * p.D, d->gdict, s);
 }

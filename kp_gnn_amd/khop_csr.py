@@ -23,13 +23,34 @@ class KHopCSR:
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
                  "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
-                 "device")
+                 "_dict_packs", "_tile_lists", "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
 
     def __init__(self):
         self._dis = None
         self._apairs = {}
+        self._dict_packs = {}   # ops.dict_tile_pack: uid-sorted dictionary entries per tile, keyed by the uid tensor
+        self._tile_lists = {}   # tile_list(k): hop-prefix copies of (tile_ptr, tile_pack)
+
+    def tile_list(self, k_active):
+        """(tile_ptr, tile_pack) restricted to hops < k_active (kpgnn_tile_pack_filter): what kpgnn_table_grad walks for a
+        layer that aggregates a hop prefix.  Static per batch; built on first use and kept."""
+        if k_active >= self.K:
+            return self.tile_ptr, self.tile_pack
+        hit = self._tile_lists.get(k_active)
+        if hit is None:
+            from . import _lib
+            ntiles = self.tile_ptr.numel() - 1
+            optr = torch.empty_like(self.tile_ptr)
+            opack = torch.empty_like(self.tile_pack)
+            scratch = torch.empty(max(ntiles, 1), dtype=torch.int32, device=self.tile_ptr.device)
+            with torch.cuda.device(self.tile_ptr.device):
+                _lib.check(_lib.load().kpgnn_tile_pack_filter(
+                    self.tile_ptr.data_ptr(), self.tile_pack.data_ptr(), ntiles, k_active, optr.data_ptr(), opack.data_ptr(),
+                    scratch.data_ptr(), torch.cuda.current_stream().cuda_stream), "kpgnn_tile_pack_filter")
+            hit = self._tile_lists[k_active] = (optr, opack)
+        return hit
 
     def active_pairs(self, k_active):
         """Number of active (edge,hop) pairs within the first k_active hops (== A for k_active == K).

@@ -225,6 +225,56 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     return gx, gt0, gtk
 
 
+def dict_tile_pack(csr, uid):
+    """The (node, hop) dictionary entries of every tile of `csr`, sorted by dictionary row (kpgnn_dict_tile_pack): static
+    per batch, built on first use and kept on the csr.  `uid` may be a hop-prefix view uid_full[:, :k]: the list is built
+    over the full row (the kernel skips hops >= k).  Returns (pack, K_built) or (None, 0) when the shape has no pack."""
+    kf = uid.stride(0) if uid.dim() == 2 and uid.shape[0] > 1 else uid.shape[1]
+    if uid.stride(1) != 1 or kf > 8 or kf < uid.shape[1] or csr.nodes_per_tile * kf > 64:
+        return None, 0
+    cache = csr._dict_packs
+    key = (uid.data_ptr(), kf, uid.shape[0])
+    hit = cache.get(key)
+    if hit is None:
+        N = uid.shape[0]
+        tiles = (N + csr.nodes_per_tile - 1) // csr.nodes_per_tile
+        pack = torch.empty((tiles, 64), dtype=torch.int32, device=uid.device)
+        with torch.cuda.device(uid.device):
+            _lib.check(_lib.load().kpgnn_dict_tile_pack(uid.data_ptr(), kf, N, kf, csr.nodes_per_tile, pack.data_ptr(),
+                                                        _stream(uid)), "kpgnn_dict_tile_pack")
+        hit = cache[key] = (pack, kf, uid)     # (uid kept alive: the key is its address)
+    return hit[0], hit[1]
+
+
+def dict_grad_raw(uid, n_dict, theta, gh):
+    """Launch kpgnn_dict_grad: gdict[u] = sum_k theta[k] * sum_{i: uid[i,k]==u} gh[i].  uid [N,k] (may be a hop-prefix
+    view), theta [k,D], gh [N,D].  Returns gdict [n_dict,D], or None when the shape does not fit the kernel."""
+    lib = _lib.load()
+    N, K = uid.shape
+    D = gh.shape[1]
+    ws_bytes = lib.kpgnn_dict_grad_workspace_bytes(N, K, D, n_dict)
+    if ws_bytes == 0 or uid.stride(1) != 1:
+        return None
+    dev = gh.device
+    gh = gh.contiguous()
+    theta = theta.contiguous()
+    d = _lib.DictGradDesc()
+    d.N, d.K, d.D, d.n_dict = N, K, D, n_dict
+    d.uid, d.uid_stride, d.theta, d.gh = uid.data_ptr(), uid.stride(0), theta.data_ptr(), gh.data_ptr()
+    gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+    d.gdict, d.workspace, d.workspace_bytes = gd.data_ptr(), ws.data_ptr(), int(ws_bytes)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_dict_grad(ctypes.byref(d), _stream(gh)), "kpgnn_dict_grad")
+        if _timer is not None:
+            e1.record()
+            _timer.records.append(("dict_grad", 4 * N * D + 4 * N * K + 4 * D * (n_dict + K), e0, e1))
+    return gd
+
+
 def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
@@ -245,7 +295,8 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
     d.kernel = kernel
     if edges:
-        d.tile_ptr, d.tile_pack = csr.tile_ptr.data_ptr(), csr.tile_pack.data_ptr()
+        tptr, tpack = csr.tile_list(K)          # (hop-prefix copy of the entry list when this layer sees K < csr.K hops)
+        d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
     d.g = g.data_ptr()
     d.g_sn, d.g_sk = K * D, D  # (contiguous; size-1 dims carry arbitrary strides)
     gt0 = gtk = gd = None
@@ -257,6 +308,9 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
         d.uid, d.uid_stride, d.gdict = uid.data_ptr(), uid.stride(0), gd.data_ptr()
         d.theta, d.gh = _ptr(theta), _ptr(gh)
+        if K <= 8 and csr.nodes_per_tile * K <= 64:
+            pack, kf = dict_tile_pack(csr, uid)
+            d.dict_pack, d.dict_pack_K = _ptr(pack), kf
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
     d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
     with torch.cuda.device(dev):
@@ -395,12 +449,16 @@ class KHopAggregate(torch.autograd.Function):
             edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
             dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
             res = None
+            if dict_here and fused:               # from gh alone (20 MB instead of riding along the [N,K,D] walk)
+                gdict = dict_grad_raw(uid, ctx.n_dict, theta, gout)
+                dict_here = gdict is None
             if edges_here or dict_here:
                 res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
                                      uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
                                      theta=theta if fused else None, gh=gout if fused else None)
             if res is not None:
-                gt0, gtk, gdict = res
+                gt0, gtk = res[0], res[1]
+                gdict = res[2] if gdict is None else gdict
             if want_tables and (res is None or not edges_here):
                 tables_in_gather = True
             if want_gdict and gdict is None:  # activation without fused combine (or oversize tables): dL/dP = gout

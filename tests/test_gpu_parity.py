@@ -778,6 +778,69 @@ def test_table_grad_kernels_agree_with_index_add(kernel, D, dict_mode):
         _close(gd, refd, "gdict", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("k_act", [1, 3, 8])
+@pytest.mark.parametrize("D", [104, 13])
+def test_table_grad_walk_hop_prefix_sorted_dictionary_bitwise(k_act, D, monkeypatch):
+    """The register walk on a hop prefix (g [N,k,D], uid[:, :k] view of the [N,8] ids): skewed ids and codes so that runs
+    of one row span several waves' chunks (the owner/follower hand-over), with the uid-sorted tile list
+    (kpgnn_dict_tile_pack); the result is bitwise repeatable; without the list the launch goes to the count-matrix kernel."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(100 * k_act + D)
+    N, K, E, U = 1237, 8, 30000, 11
+    ei = torch.randint(0, N, (2, E), generator=g0)
+    code = (torch.rand(E, K, generator=g0) ** 4 * 5).long() + 1          # mostly code 1: long runs
+    ea = code * (torch.rand(E, K, generator=g0) < 0.5)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    uid_full = ((torch.rand(N, K, generator=g0) ** 3) * U).to(torch.int32).to(dev)   # row 0 dominates
+    uid = uid_full[:, :k_act]
+    gt = torch.randn(N, k_act, D, generator=g0)
+    theta = torch.rand(k_act, D, generator=g0)
+    gh = torch.randn(N, D, generator=g0)
+    kw = dict(uid=uid, n_dict=U, theta=theta.to(dev), gh=gh.to(dev), kernel=1)
+    a = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **kw)
+    b = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **kw)
+    assert csr._dict_packs, "the sorted dictionary list was not built"
+    for x, y in zip(a, b):
+        if x is not None:
+            assert torch.equal(x, y), "table_grad is not bitwise repeatable"
+    monkeypatch.setattr(ops, "dict_tile_pack", lambda csr, uid: (None, 0))
+    with pytest.raises(Exception, match="uid-sorted list"):      # the walk refuses an unsorted dictionary list ...
+        ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **kw)
+    c = ops.table_grad_raw(csr, gt.to(dev), 6, 6, edges=True, **dict(kw, kernel=0))   # ... which goes to the count-matrix kernel
+    e, k = torch.nonzero(ea[:, :k_act], as_tuple=True)
+    rows = gt[ei[1][e], k]
+    cd = ea[e, k]
+    ref0 = torch.zeros(6, D).index_add_(0, cd[k == 0], rows[k == 0])
+    refk = torch.zeros(6, D).index_add_(0, cd[k > 0], rows[k > 0])
+    refd = torch.zeros(U, D).index_add_(0, uid.cpu().reshape(-1).long(), (theta.unsqueeze(0) * gh.unsqueeze(1)).reshape(-1, D))
+    for res in (a, c):
+        _close(res[0], ref0, "gtable0", rtol=2e-4, atol=2e-4)
+        if k_act > 1:
+            _close(res[1], refk, "gtablek", rtol=2e-4, atol=2e-4)
+        _close(res[2], refd, "gdict", rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("N,k_act,D,U", [(1237, 8, 104, 11), (4099, 3, 104, 25), (37, 1, 64, 3), (700, 6, 96, 40), (513, 8, 26, 7)])
+def test_dict_grad_matches_index_add_bitwise(N, k_act, D, U):
+    """kpgnn_dict_grad (dictionary gradient from gh alone, one wave per hop) against index_add_ of theta[k]*gh[i] on the same
+    ids; hop-prefix view of a wider id table; bitwise repeatable; agrees with kpgnn_table_grad's dictionary path."""
+    from kp_gnn_amd import ops
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(N + k_act)
+    uid_full = ((torch.rand(N, 8, generator=g0) ** 3) * U).to(torch.int32).to(dev)
+    uid = uid_full[:, :k_act]
+    theta = torch.rand(k_act, D, generator=g0)
+    gh = torch.randn(N, D, generator=g0)
+    a = ops.dict_grad_raw(uid, U, theta.to(dev), gh.to(dev))
+    b = ops.dict_grad_raw(uid, U, theta.to(dev), gh.to(dev))
+    assert a is not None and torch.equal(a, b)
+    ref = torch.zeros(U, D).index_add_(0, uid.cpu().reshape(-1).long(), (theta.unsqueeze(0) * gh.unsqueeze(1)).reshape(-1, D))
+    _close(a, ref, "gdict", rtol=2e-4, atol=2e-4)
+    assert ops.dict_grad_raw(uid, 4000, theta.to(dev), gh.to(dev)) is None      # does not fit LDS: the caller falls back
+
+
 # ----------------------------------------------------------------------------- hipGraph capture: replay == eager
 def _small_body(model_name, combine, K, L, H):
     import argparse
