@@ -220,6 +220,12 @@ typedef struct kpgnn_table_grad_desc {
      * bitwise reproducible).  Without it a dictionary gradient goes to the count-matrix kernel. */
     const uint32_t* dict_pack;
     int32_t dict_pack_K;
+    /* Optional: a second slab [extra_nslab][extra_elems] (e.g. the one kpgnn_dict_grad left with defer_reduce) that the
+     * finishing launch adds up into extra_out[extra_elems] as well - one launch instead of two. */
+    const float* extra_slab;
+    int32_t extra_nslab;
+    int64_t extra_elems;
+    float* extra_out;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
@@ -247,9 +253,14 @@ typedef struct kpgnn_dict_grad_desc {
     float* gdict;               /* device [n_dict, D] (overwritten) */
     void* workspace;            /* device, >= kpgnn_dict_grad_workspace_bytes(N, K, D, n_dict) */
     size_t workspace_bytes;
+    /* defer_reduce != 0: leave the per-block partial sums in workspace as float[kpgnn_dict_grad_slabs(N)][n_dict*D] and
+     * do not write gdict: the caller adds them up in block order (kpgnn_table_grad's extra_slab does it in its own
+     * finishing launch). */
+    int32_t defer_reduce;
 } kpgnn_dict_grad_desc;
 
 size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t n_dict);
+int32_t kpgnn_dict_grad_slabs(int32_t N);
 int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t stream);
 
 /* Backward pre-pass of the fused epilogue (elementwise, streaming):  with v = act(S) + P,
@@ -276,6 +287,10 @@ typedef struct kpgnn_combine_bwd_desc {
     void* workspace;            /* device, >= kpgnn_combine_bwd_workspace_bytes(N,K,D) when gtheta != NULL */
     size_t workspace_bytes;
     int32_t n_dict;             /* rows of ptab (0 = unknown): small dictionaries are staged in LDS */
+    /* Geometric combine (theta = softmax_k(a (1-a)^k), a = sigmoid(alphas), layers/combine.py:43-50): with both given the
+     * launch that adds up gtheta also writes galphas[D] = (d theta / d alphas)^T gtheta (kpgnn_geo_theta_bwd's result). */
+    const float* alphas;        /* device [D] or NULL */
+    float* galphas;             /* device [D] or NULL */
 } kpgnn_combine_bwd_desc;
 
 size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D);

@@ -55,6 +55,7 @@ class TableGradDesc(ctypes.Structure):
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("kernel", c_i32),
         ("dict_pack", c_vp), ("dict_pack_K", c_i32),
+        ("extra_slab", c_vp), ("extra_nslab", c_i32), ("extra_elems", c_i64), ("extra_out", c_vp),
     ]
 
 
@@ -62,7 +63,7 @@ class DictGradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i32), ("K", c_i32), ("D", c_i32), ("n_dict", c_i32),
         ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp), ("gdict", c_vp),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("defer_reduce", c_i32),
     ]
 
 
@@ -75,6 +76,7 @@ class CombineBwdDesc(ctypes.Structure):
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("g", c_vp), ("gv", c_vp), ("gtheta", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("n_dict", c_i32),
+        ("alphas", c_vp), ("galphas", c_vp),
     ]
 
 
@@ -192,6 +194,7 @@ SIGNATURES = {
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
     "kpgnn_dict_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 4),
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
+    "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),

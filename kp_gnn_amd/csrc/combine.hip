@@ -228,6 +228,7 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     KPGNN_REQUIRE(d->pre && d->g, "combine_bwd: NULL pre/g");
     KPGNN_REQUIRE(d->theta ? d->gh != nullptr : d->gout != nullptr, "combine_bwd: need (theta, gh) or gout");
     KPGNN_REQUIRE(d->gtheta == nullptr || d->theta != nullptr, "combine_bwd: gtheta without theta");
+    KPGNN_REQUIRE(!d->galphas || (d->alphas && d->gtheta), "combine_bwd: galphas needs alphas and gtheta");
     KPGNN_REQUIRE(d->mode >= KPGNN_MODE_GIN && d->mode <= KPGNN_MODE_SUM, "combine_bwd: unknown mode %d", d->mode);
     int vec = 1, g = 4;
     int rc = cb_shape(d, &vec, &g);
@@ -256,6 +257,8 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     }
 #undef KP_CB
     if (rc != KPGNN_OK) return rc;
+    if (p.slab && d->alphas && d->galphas)    // geometric combine: the finishing launch also differentiates theta(alphas)
+        return gtheta_finish_launch(p.slab, grid, d->alphas, d->theta, d->K, d->D, d->gtheta, d->galphas, s);
     if (p.slab) return slab_reduce(p.slab, grid, (int64_t)d->K * d->D, d->gtheta, (int64_t)d->K * d->D, nullptr, 0, nullptr, s);
     return KPGNN_OK;
 }

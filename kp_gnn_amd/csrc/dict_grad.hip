@@ -21,7 +21,7 @@ namespace {
 
 constexpr int kWavesDG = 8;
 constexpr int kThreadsDG = kWave * kWavesDG;
-constexpr int kChunk = 32;                  // nodes per staged chunk of gh
+constexpr int kChunk = 64;                  // nodes per staged chunk of gh
 
 struct DgParams {
     int N, K, D, U;
@@ -46,12 +46,13 @@ dict_grad_kernel(const DgParams p) {
     for (int i = threadIdx.x; i < U * K * D; i += kThreadsDG) acc[i] = 0.f;
     const int per = (p.N + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * per, n1 = min(p.N, n0 + per);
-    const int chunk_floats = kChunk * D;              // multiple of 4 (D even, kChunk 32)
-    // chunk staging: thread t copies float4 t and t + 512 of the chunk (kChunk*D/4 <= 1024 float4: D <= 128)
-    float4 pre[2];
+    const int chunk_floats = kChunk * D;              // multiple of 4 (D even, kChunk 64)
+    // chunk staging: thread t copies float4 t, t + 512, ... of the chunk (kChunk*D/4 <= 2048 float4: D <= 128)
+    constexpr int kPre = 4;
+    float4 pre[kPre];
     auto load_chunk = [&](int node0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kPre; ++q) {
             const int i = (q * kThreadsDG + threadIdx.x) * 4;
             pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < chunk_floats && node0 + i / D < n1)     // (D % 4 == 0 on this path: a float4 never straddles two rows)
@@ -90,7 +91,7 @@ dict_grad_kernel(const DgParams p) {
         uidv = nuid;
         if (vec_ok) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < kPre; ++q) {
                 const int i = (q * kThreadsDG + threadIdx.x) * 4;
                 if (i < chunk_floats) *reinterpret_cast<float4*>(gs + i) = pre[q];
             }
@@ -160,13 +161,18 @@ extern "C" size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t 
     return dg_plan(N, K, D, n_dict, &pl) ? pl.ws_bytes : 0;
 }
 
+extern "C" int32_t kpgnn_dict_grad_slabs(int32_t N) {
+    DgPlan pl;
+    return (N >= 1 && dg_plan(N, 1, 2, 1, &pl)) ? pl.grid : 0;
+}
+
 extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "dict_grad: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->D >= 1 && d->n_dict >= 1, "dict_grad: bad N=%d K=%d D=%d n_dict=%d", d->N, d->K,
                   d->D, d->n_dict);
-    KPGNN_REQUIRE(d->gdict != nullptr, "dict_grad: NULL gdict");
+    KPGNN_REQUIRE(d->gdict != nullptr || d->defer_reduce, "dict_grad: NULL gdict");
     hipStream_t s = (hipStream_t)stream;
-    if (d->N == 0) { KPGNN_HIP_TRY(hipMemsetAsync(d->gdict, 0, sizeof(float) * (size_t)d->n_dict * d->D, s)); return KPGNN_OK; }
+    if (d->N == 0) { if (d->defer_reduce) return fail(KPGNN_EINVAL, "dict_grad: defer_reduce with N == 0"); KPGNN_HIP_TRY(hipMemsetAsync(d->gdict, 0, sizeof(float) * (size_t)d->n_dict * d->D, s)); return KPGNN_OK; }
     DgPlan pl;
     if (!dg_plan(d->N, d->K, d->D, d->n_dict, &pl))
         return fail(KPGNN_ELIMIT, "dict_grad: K=%d (<= 8), even D=%d (<= 128) and n_dict*K*D*4 + staging <= 160 KB of LDS needed "
@@ -180,5 +186,6 @@ extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t str
     if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)dict_grad_kernel, pl.lds));
     hipLaunchKernelGGL(dict_grad_kernel, dim3(pl.grid), dim3(kThreadsDG), pl.lds, s, p);
     KPGNN_LAUNCH_CHECK("dict_grad_kernel");
+    if (d->defer_reduce) return KPGNN_OK;
     return slab_reduce(p.slab, pl.grid, (int64_t)p.U * p.D, d->gdict, (int64_t)p.U * p.D, nullptr, 0, nullptr, s);
 }

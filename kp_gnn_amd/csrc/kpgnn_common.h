@@ -55,11 +55,16 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).
+// Optionally the same launch reduces a second, independent slab [nslab_b][elems_b] into out_b.
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
-                float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr);
+                float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr, const float* slab_b = nullptr,
+                int nslab_b = 0, int64_t elems_b = 0, float* out_b = nullptr);
 
 // theta[k,d] = softmax_k(a (1-a)^k), a = sigmoid(alpha[d])  (geo_theta.hip)
 int geo_theta_fwd_launch(const float* alpha, int K, int D, float* theta, hipStream_t s);
+// gtheta[k,d] = sum_b slab[b][k,d] (block order) and galpha = d(theta)/d(alpha)^T gtheta, one launch (geo_theta.hip)
+int gtheta_finish_launch(const float* slab, int nslab, const float* alpha, const float* theta, int K, int D, float* gtheta,
+                         float* galpha, hipStream_t s);
 
 // Count-matrix x g-tile table gradients on the matrix cores (table_grad_mfma.hip): *handled tells whether the launch
 // was done; otherwise kpgnn_table_grad falls back to its register-walk kernel.

@@ -412,10 +412,17 @@ dict_tile_pack_kernel(const int32_t* __restrict__ uid, int64_t uid_stride, int N
 __global__ void __launch_bounds__(1024)
 slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, float* __restrict__ out0, int64_t n_out0,
                    float* __restrict__ out1, int64_t n_out1, float* __restrict__ out2, int64_t n_out2,
-                   float* __restrict__ out3) {
+                   float* __restrict__ out3, int nblocks_a, const float* __restrict__ slab_b, int nslab_b, int64_t elems_b,
+                   float* __restrict__ out_b) {
     __shared__ float part[64][17];
     const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int64_t e = (int64_t)blockIdx.x * 16 + o;
+    int64_t blk = blockIdx.x;
+    if (blk >= nblocks_a) {           // the blocks behind the first slab's reduce a second, independent slab into out_b
+        blk -= nblocks_a;
+        slab = slab_b; nslab = nslab_b; elems = elems_b;
+        out0 = out_b; n_out0 = elems_b;
+    }
+    const int64_t e = blk * 16 + o;
     float s = 0.f;
     if (e < elems) {
         int b = slice;
@@ -442,11 +449,15 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
 }  // namespace
 
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
-                float* out2, hipStream_t s, int64_t n2, float* out3) {
-    if (elems <= 0) return KPGNN_OK;
+                float* out2, hipStream_t s, int64_t n2, float* out3, const float* slab_b, int nslab_b, int64_t elems_b,
+                float* out_b) {
+    if (!slab_b || elems_b <= 0) { slab_b = nullptr; elems_b = 0; }
+    if (elems <= 0 && elems_b <= 0) return KPGNN_OK;
+    if (elems < 0) elems = 0;
     if (!out3) n2 = elems;   // three outputs: the rest goes to out2
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems + 15) / 16)), dim3(1024), 0, s, slab, nslab, elems,
-                       out0, n0, out1, n1, out2, n2, out3);
+    const int nba = (int)((elems + 15) / 16), nbb = (int)((elems_b + 15) / 16);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nba + nbb)), dim3(1024), 0, s, slab, nslab, elems,
+                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b);
     KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
     return KPGNN_OK;
 }
@@ -528,6 +539,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->n_dict == 0 || !d->dict_pack || (d->dict_pack_K >= d->K && d->dict_pack_K <= 8),
                   "table_grad: dict_pack was built for %d hops, g has %d", d->dict_pack_K, d->K);
     KPGNN_REQUIRE(edges || d->n_dict > 0, "table_grad: nothing to do");
+    KPGNN_REQUIRE(!d->extra_slab || (d->extra_out && d->extra_nslab >= 1 && d->extra_elems >= 1), "table_grad: bad extra slab");
     hipStream_t s = (hipStream_t)stream;
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
@@ -542,7 +554,10 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
-            if (rc != KPGNN_OK || handled) return rc;
+            if (rc != KPGNN_OK) return rc;
+            if (handled)
+                return d->extra_slab ? slab_reduce(d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out, d->extra_elems,
+                                                   nullptr, 0, nullptr, s) : KPGNN_OK;
         }
     }
     TgParams p;
@@ -566,5 +581,5 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     else rc = vec4 ? launch_walk<1, true>(p, pl, s) : launch_walk<1, false>(p, pl, s);
     if (rc != KPGNN_OK) return rc;
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
-                       (int64_t)p.nk * p.D, d->gdict, s);
+                       (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
 }

@@ -246,9 +246,11 @@ def dict_tile_pack(csr, uid):
     return hit[0], hit[1]
 
 
-def dict_grad_raw(uid, n_dict, theta, gh):
+def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     """Launch kpgnn_dict_grad: gdict[u] = sum_k theta[k] * sum_{i: uid[i,k]==u} gh[i].  uid [N,k] (may be a hop-prefix
-    view), theta [k,D], gh [N,D].  Returns gdict [n_dict,D], or None when the shape does not fit the kernel."""
+    view), theta [k,D], gh [N,D].  Returns gdict [n_dict,D], or None when the shape does not fit the kernel.
+    defer=True: returns (gdict, slab, nslab) with gdict still UNWRITTEN - the per-block partial sums wait in `slab` for a
+    later finishing launch (table_grad_raw(extra=...) adds them up along with its own)."""
     lib = _lib.load()
     N, K = uid.shape
     D = gh.shape[1]
@@ -264,6 +266,7 @@ def dict_grad_raw(uid, n_dict, theta, gh):
     gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
     d.gdict, d.workspace, d.workspace_bytes = gd.data_ptr(), ws.data_ptr(), int(ws_bytes)
+    d.defer_reduce = 1 if defer else 0
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -272,10 +275,12 @@ def dict_grad_raw(uid, n_dict, theta, gh):
         if _timer is not None:
             e1.record()
             _timer.records.append(("dict_grad", 4 * N * D + 4 * N * K + 4 * D * (n_dict + K), e0, e1))
+    if defer:
+        return gd, ws, int(lib.kpgnn_dict_grad_slabs(N))
     return gd
 
 
-def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0):
+def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0, extra=None):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
     kernel: 0 automatic, 1 register walk, 2 count-matrix product (parity tests).
@@ -313,6 +318,8 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
             d.dict_pack, d.dict_pack_K = _ptr(pack), kf
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
     d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+    if extra is not None:       # (out, slab, nslab) of dict_grad_raw(defer=True): added up by this call's finishing launch
+        d.extra_out, d.extra_slab, d.extra_nslab, d.extra_elems = extra[0].data_ptr(), extra[1].data_ptr(), extra[2], extra[0].numel()
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -325,9 +332,9 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     return gt0, gtk, gd
 
 
-def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want_gv):
+def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want_gv, alphas=None):
     """Launch kpgnn_combine_bwd.  gout is gh [N,D] when theta is given, else dL/dout [N,K,D].
-    Returns (g, gv or None, gtheta or None)."""
+    Returns (g, gv or None, gtheta or None); with `alphas` (geometric combine) the third is (gtheta, galphas)."""
     lib = _lib.load()
     N, K, D = pre.shape
     dev = pre.device
@@ -347,7 +354,10 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
     gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
     gth = torch.empty((K, D), dtype=torch.float32, device=dev) if want_gtheta else None
     d.g, d.gv, d.gtheta = g.data_ptr(), _ptr(gv), _ptr(gth)
-    ws = None
+    ws = gal = None
+    if want_gtheta and alphas is not None:
+        gal = torch.empty_like(alphas)
+        d.alphas, d.galphas = alphas.data_ptr(), gal.data_ptr()
     if want_gtheta:
         nb = lib.kpgnn_combine_bwd_workspace_bytes(N, K, D)
         ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
@@ -361,6 +371,8 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
             e1.record()
             n_t = 2 + (gv is not None) + (theta is None) + (periph is not None and want_gtheta)
             _timer.records.append(("combine_bwd", 4 * N * K * D * n_t + (4 * N * D if theta is not None else 0), e0, e1))
+    if gal is not None:
+        return g, gv, (gth, gal)
     return g, gv, gth
 
 
@@ -427,6 +439,7 @@ class KHopAggregate(torch.autograd.Function):
     def backward(ctx, gout):
         pre, eps, theta, periph, x_saved, xbias, ptab = ctx.saved_tensors
         mode, csr, k_act, uid = ctx.mode, ctx.csr, ctx.k_act, ctx.uid
+        galphas_done = False
         fused = theta is not None
         need_act = mode in (MODE_GINPLUS, MODE_GCN)
         want_gperiph = ctx.has_periph and ctx.needs_input_grad[3]
@@ -437,7 +450,10 @@ class KHopAggregate(torch.autograd.Function):
         if fused or need_act:
             g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
                                             want_gtheta=fused and ctx.needs_input_grad[5],
-                                            want_gv=fused and want_gperiph)
+                                            want_gv=fused and want_gperiph, alphas=ctx.alphas if fused else None)
+            if isinstance(gtheta, tuple):            # geometric combine: d/dalphas came with the same finishing launch
+                gtheta = gtheta[1]
+                galphas_done = True
             gperiph = gv if fused else (gout if want_gperiph else None)
         else:
             g = gout
@@ -449,13 +465,24 @@ class KHopAggregate(torch.autograd.Function):
             edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
             dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
             res = None
-            if dict_here and fused:               # from gh alone (20 MB instead of riding along the [N,K,D] walk)
-                gdict = dict_grad_raw(uid, ctx.n_dict, theta, gout)
-                dict_here = gdict is None
+            extra = None
+            # (below ~4K nodes the walk's own dictionary path is cheaper than a second kernel: 1.44 vs 1.52 ms per step at
+            #  batch 64, where every launch is latency-bound)
+            if dict_here and fused and (g.shape[0] >= 4096 or not edges_here):   # from gh alone (20 MB, not [N,K,D])
+                # (its partial sums are added up by table_grad's finishing launch when one follows)
+                dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=edges_here)
+                if dg is not None:
+                    dict_here = False
+                    if edges_here:
+                        gdict, extra = dg[0], dg
+                    else:
+                        gdict = dg
             if edges_here or dict_here:
                 res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
                                      uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
-                                     theta=theta if fused else None, gh=gout if fused else None)
+                                     theta=theta if fused else None, gh=gout if fused else None, extra=extra)
+                if res is None and extra is not None:
+                    raise _lib.KpgnnError("table_grad refused a shape after dict_grad deferred its reduction to it")
             if res is not None:
                 gt0, gtk = res[0], res[1]
                 gdict = res[2] if gdict is None else gdict
@@ -472,7 +499,7 @@ class KHopAggregate(torch.autograd.Function):
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
         if tables_in_gather:
             gt0, gtk = a0, ak
-        if gtheta is not None and ctx.alphas is not None:   # d/dalphas through theta (geo_theta.hip), one tiny launch
+        if gtheta is not None and ctx.alphas is not None and not galphas_done:   # d/dalphas through theta (geo_theta.hip)
             galpha = torch.empty_like(ctx.alphas)
             lib = _lib.load()
             with torch.cuda.device(galpha.device):
