@@ -165,7 +165,8 @@ def pmc_traffic(args, kernel):
     collected and corrected).  It is only reported when the workload AND the kernel sources (csrc digest) are the ones
     that were profiled; otherwise null - a stale figure next to fresh timings would be worse than none."""
     path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    key = f"{args.workload}|{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}"
+    key = f"{args.workload}|{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}" \
+        + ("" if args.dtype == "f32" else "|" + args.dtype)
     try:
         with open(path) as fh:
             j = json.load(fh)
@@ -232,6 +233,9 @@ def main():
     ap.add_argument("--K", type=int, default=None)
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="storage of the K-hop streams (hop-slot rows, saved S, dL/dS): bf16 = 2-byte rows with fp32 sums "
+                         "(KPGNN_STORE_BF16, KP-GIN+ path); every parameter, state and accumulator stays fp32")
     ap.add_argument("--dense-peripheral", action="store_true",
                     help="hand the layers the dense [N,K,D] peripheral tensor instead of its dictionary form")
     ap.add_argument("--cpu-graphs", type=int, default=128)
@@ -276,6 +280,11 @@ def main():
     from kp_gnn_amd import dp
     if args.dense_peripheral:
         B.MAX_DICT_ROWS = 0
+    if args.dtype == "bf16":
+        if args.model != "KPGINPlus" or args.combine != "geometric" or args.dense_peripheral or args.hidden % 8:
+            raise SystemExit("--dtype bf16: the bf16-storage kernels exist for KPGINPlus + geometric combine + dictionary "
+                             "peripheral features with hidden % 8 == 0")
+        ops.set_storage_dtype(torch.bfloat16)
 
     threads = max(1, usable_cpus() // max(1, min(world, 8)))
     torch.set_num_threads(threads)
@@ -359,7 +368,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 storage of the K-hop streams (hop-slot rows, S, dL/dS), f32 accumulate / parameters / states",
+            "data": "synthetic",
             "config": {"workload": f"{desc}, {args.model} K={args.K} L={args.layers} h={args.hidden} kernel={args.kernel}"
                                    + (f" {args.combine} combine" if args.train else "") + f", {what}"
                                    + (", dense peripheral tensor" if args.dense_peripheral else ""),

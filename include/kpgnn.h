@@ -93,6 +93,13 @@ int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, i
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
+/* Storage of the big per-(node,hop) streams.  KPGNN_STORE_BF16: the rows a launch reads or writes as marked "(storage)"
+ * below hold bf16 (2 bytes per element, same shapes and ELEMENT strides); every sum, the tables, theta, P and the layer
+ * outputs stay fp32.  Implemented for the KP-GIN+ training path (fused GELU + geometric combine, dictionary P, D % 4 == 0):
+ * kpgnn_aggregate_fwd (x_slot rows, pre), kpgnn_combine_bwd (pre, g), kpgnn_table_grad (g), kpgnn_aggregate_bwd (g);
+ * other configurations answer KPGNN_EINVAL.  (BASELINE configs[1] names bf16; tolerance 2e-2 relative) */
+enum { KPGNN_STORE_F32 = 0, KPGNN_STORE_BF16 = 1 };
+
 enum {
     KPGNN_MODE_GIN = 0,     /* out = S + P + (1+eps)*x                  KPGIN.py:100-105, gine.py:52-53 */
     KPGNN_MODE_GINPLUS = 1, /* out = gelu(S) + P                        KPGINplus.py:74-77,87-88        */
@@ -149,6 +156,9 @@ typedef struct kpgnn_agg_fwd_desc {
     /* Geometric combine computed by the launch itself: alphas [D] (device) - theta[k,d] = softmax_k(a (1-a)^k) with
      * a = sigmoid(alphas[d]) (combine.py:43-50) is then an OUTPUT, written to `theta` ([K,D]) for the backward. */
     const float* alphas;
+    /* KPGNN_STORE_*: with BF16 the x_slot rows (storage) and pre (storage) are bf16 - pass them through these float
+     * pointers; x_sn counts ELEMENTS. */
+    int32_t storage;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
@@ -178,6 +188,7 @@ typedef struct kpgnn_agg_bwd_desc {
      * a slot collects its gradient in one buffer instead of one tensor per reader plus an add each).  Two hop slots of
      * one call must not share a buffer when either accumulates (KPGNN_EINVAL). */
     uint32_t accumulate_mask;
+    int32_t storage;            /* KPGNN_STORE_*: with BF16, g (storage) holds bf16 rows; g_sn / g_sk count elements */
 } kpgnn_agg_bwd_desc;
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
@@ -226,6 +237,7 @@ typedef struct kpgnn_table_grad_desc {
     int32_t extra_nslab;
     int64_t extra_elems;
     float* extra_out;
+    int32_t storage;            /* KPGNN_STORE_*: with BF16, g (storage) holds bf16 rows (walk kernel, D % 8 == 0) */
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
@@ -291,6 +303,7 @@ typedef struct kpgnn_combine_bwd_desc {
      * launch that adds up gtheta also writes galphas[D] = (d theta / d alphas)^T gtheta (kpgnn_geo_theta_bwd's result). */
     const float* alphas;        /* device [D] or NULL */
     float* galphas;             /* device [D] or NULL */
+    int32_t storage;            /* KPGNN_STORE_*: with BF16, pre (storage) and g (storage) hold bf16 rows */
 } kpgnn_combine_bwd_desc;
 
 size_t kpgnn_combine_bwd_workspace_bytes(int32_t N, int32_t K, int32_t D);

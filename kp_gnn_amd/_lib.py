@@ -27,7 +27,7 @@ class AggFwdDesc(ctypes.Structure):
         ("out", c_vp), ("o_sn", c_i64), ("o_sk", c_i64),
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
-        ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp),
+        ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp), ("storage", c_i32),
     ]
 
 
@@ -40,7 +40,7 @@ class AggBwdDesc(ctypes.Structure):
         ("eps", c_vp),
         ("gx", c_vp), ("gx_sn", c_i64), ("gx_sk", c_i64),
         ("gtable0", c_vp), ("gtablek", c_vp),
-        ("gx_slot", c_vp * 16), ("accumulate_mask", ctypes.c_uint32),
+        ("gx_slot", c_vp * 16), ("accumulate_mask", ctypes.c_uint32), ("storage", c_i32),
     ]
 
 
@@ -55,7 +55,7 @@ class TableGradDesc(ctypes.Structure):
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("kernel", c_i32),
         ("dict_pack", c_vp), ("dict_pack_K", c_i32),
-        ("extra_slab", c_vp), ("extra_nslab", c_i32), ("extra_elems", c_i64), ("extra_out", c_vp),
+        ("extra_slab", c_vp), ("extra_nslab", c_i32), ("extra_elems", c_i64), ("extra_out", c_vp), ("storage", c_i32),
     ]
 
 
@@ -76,7 +76,7 @@ class CombineBwdDesc(ctypes.Structure):
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("g", c_vp), ("gv", c_vp), ("gtheta", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("n_dict", c_i32),
-        ("alphas", c_vp), ("galphas", c_vp),
+        ("alphas", c_vp), ("galphas", c_vp), ("storage", c_i32),
     ]
 
 

@@ -50,6 +50,11 @@ template <int VEC> struct V {
     __device__ __forceinline__ void store_stream(float* p) const {
         for (int i = 0; i < VEC; ++i) __builtin_nontemporal_store(v[i], p + i);
     }
+    // a row stored as bf16 (BF) or fp32: `p` is a byte address
+    template <bool BF> __device__ __forceinline__ static V load_row(const char* p) {
+        if (BF) { V r; ld_bf16<VEC>(p, r.v); return r; }
+        return load(reinterpret_cast<const float*>(p));
+    }
     __device__ __forceinline__ void add(const V& o) { for (int i = 0; i < VEC; ++i) v[i] += o.v[i]; }
     __device__ __forceinline__ void fma(float s, const V& o) { for (int i = 0; i < VEC; ++i) v[i] = fmaf(s, o.v[i], v[i]); }
 };
@@ -60,7 +65,7 @@ __device__ __forceinline__ float gelu_exact(float x) {  // F.gelu(approximate='n
 }
 
 struct FwdParams {
-    int N, K, D, K_csr, n_code0, n_codek, mode, combine;
+    int N, K, D, K_csr, n_code0, n_codek, mode, combine, bf;
     const int32_t* rowptr;
     const int32_t* col;
     const uint16_t* code;
@@ -86,7 +91,8 @@ struct FwdParams {
 // GCN selects the weighted inner loop; the other epilogues are wave-uniform runtime switches.
 // FAST: the KP-GIN+ training configuration (GELU epilogue, fused geometric combine, dictionary P, S saved) with its
 // epilogue switches resolved at compile time.
-template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
+// BF (FAST only): the gathered hop slots (xs) and the saved S (`pre`) are bf16 rows; sums, tables, theta, P, hout fp32.
+template <int VEC, int G, bool GCN, int TAB, bool FAST = false, bool BF = false>
 __global__ void __launch_bounds__(kBlock, FAST ? 5 : 4)
 agg_fwd_kernel(const FwdParams p) {
     const int MODE = FAST ? (int)KPGNN_MODE_GINPLUS : p.mode;
@@ -141,8 +147,10 @@ agg_fwd_kernel(const FwdParams p) {
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
     const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
-    const uint32_t xrow_b = (uint32_t)p.x_sn * 4u, trow_b = (uint32_t)D * 4u;   // (host: N * x_sn * 4 < 2^32)
+    constexpr uint32_t XB = BF ? 2u : 4u;                       // bytes per stored element of a gathered row
+    const uint32_t xrow_b = (uint32_t)p.x_sn * XB, trow_b = (uint32_t)D * 4u;   // (host: N * x_sn * 4 < 2^32)
     const uint32_t lane_b = col_ok ? (uint32_t)c0 * 4u : 0u;   // idle lanes re-read column 0 and are dropped below
+    const uint32_t lane_bx = col_ok ? (uint32_t)c0 * XB : 0u;
 
     int last_u = -1;                        // dictionary row held in registers
     V<VEC> prow = V<VEC>::zero();
@@ -191,7 +199,7 @@ agg_fwd_kernel(const FwdParams p) {
                     const int l = sg_lane0 + (bpos - cbase) + u;
                     const uint32_t o = __shfl(coff, l);
                     if (TAB != 0) prb[u] = __shfl(ctab, l);
-                    pr[u] = V<VEC>::load(reinterpret_cast<const float*>(xb + (size_t)(o + lane_b)));
+                    pr[u] = V<VEC>::template load_row<BF>(xb + (size_t)(o + lane_bx));
                 }
             }
         };
@@ -246,8 +254,8 @@ agg_fwd_kernel(const FwdParams p) {
                         const uint32_t o0 = __shfl(coff, l0), o1 = __shfl(coff, l1);
                         uint32_t b0 = 0, b1 = 0;
                         if (TAB != 0) { b0 = __shfl(ctab, l0); b1 = __shfl(ctab, l1); }
-                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
-                        V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o1 + lane_b)));
+                        V<VEC> r0 = V<VEC>::template load_row<BF>(xkb + (size_t)(o0 + lane_bx));
+                        V<VEC> r1 = V<VEC>::template load_row<BF>(xkb + (size_t)(o1 + lane_bx));
                         if (TAB != 0) {
                             r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
                             r1.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b1 + lane_b))));
@@ -258,7 +266,7 @@ agg_fwd_kernel(const FwdParams p) {
                     if (t < lim) {
                         const int l0 = sg_lane0 + t;
                         const uint32_t o0 = __shfl(coff, l0);
-                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(xkb + (size_t)(o0 + lane_b)));
+                        V<VEC> r0 = V<VEC>::template load_row<BF>(xkb + (size_t)(o0 + lane_bx));
                         if (TAB != 0) {
                             const uint32_t b0 = __shfl(ctab, l0);
                             r0.add(V<VEC>::load(reinterpret_cast<const float*>(tabb + (size_t)(b0 + lane_b))));
@@ -325,7 +333,8 @@ agg_fwd_kernel(const FwdParams p) {
                 v.fma(di, self);                                          // last term of the edge list
                 for (int q = 0; q < VEC; ++q) v.v[q] *= di;
             }
-            if (FAST || p.pre) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
+            if (BF) st_bf16_stream<VEC>(reinterpret_cast<uint16_t*>(p.pre) + (i * p.K + k) * (int64_t)D + c0, v.v);
+            else if (FAST || p.pre) v.store_stream(p.pre + (i * p.K + k) * (int64_t)D + c0);
             if (MODE == KPGNN_MODE_GINPLUS) { for (int q = 0; q < VEC; ++q) v.v[q] = gelu_exact(v.v[q]); }
             if (GCN) { for (int q = 0; q < VEC; ++q) v.v[q] = fmaxf(v.v[q], 0.f); }
             if (!FAST && p.periph) v.add(V<VEC>::load(p.periph + i * p.p_sn + (int64_t)k * p.p_sk + c0));
@@ -347,7 +356,7 @@ agg_fwd_kernel(const FwdParams p) {
 }
 
 struct BwdParams {
-    int N, K, D, K_csr, n_code0, n_codek, mode;
+    int N, K, D, K_csr, n_code0, n_codek, mode, bf;
     const int32_t* rowptr;
     const int32_t* col;
     const uint16_t* code;
@@ -363,7 +372,8 @@ struct BwdParams {
 
 // TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
 //      2 = straight global atomics (tables too large for LDS)
-template <int VEC, int G, bool GCN, int TAB>
+// BF (the chunked gather, !GCN && TAB == 0, not GIN): g rows are bf16; the sums and gx stay fp32.
+template <int VEC, int G, bool GCN, int TAB, bool BF = false>
 __global__ void __launch_bounds__(kBlock, 6)
 agg_bwd_kernel(const BwdParams p) {
     const int MODE = p.mode;
@@ -386,8 +396,9 @@ agg_bwd_kernel(const BwdParams p) {
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
     const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
-    const uint32_t grow_b = (uint32_t)p.g_sn * 4u;              // (host: N * g_sn * 4 < 2^32)
-    const uint32_t lane_b = col_ok ? (uint32_t)c0 * 4u : 0u;   // idle lanes re-read column 0 and are dropped below
+    constexpr uint32_t GB = BF ? 2u : 4u;                       // bytes per stored element of g
+    const uint32_t grow_b = (uint32_t)p.g_sn * GB;              // (host: N * g_sn * 4 < 2^32)
+    const uint32_t lane_b = col_ok ? (uint32_t)c0 * GB : 0u;   // idle lanes re-read column 0 and are dropped below
 
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t j = w.cur * NODES + sg;
@@ -414,12 +425,12 @@ agg_bwd_kernel(const BwdParams p) {
         auto prefetch = [&](int kk, int bpos, int bend) {      // rows of hop kk's first pairs, requested one hop ahead
             prn = min(PF, min(bend, cbase + G) - bpos);
             if (prn < 0) prn = 0;
-            const char* gb = reinterpret_cast<const char*>(p.g + (int64_t)kk * p.g_sk);
+            const char* gb = reinterpret_cast<const char*>(p.g) + (int64_t)kk * p.g_sk * GB;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (u < prn) {
                     const uint32_t o = __shfl(coff, sg_lane0 + (bpos - cbase) + u);
-                    pr[u] = V<VEC>::load(reinterpret_cast<const float*>(gb + (size_t)(o + lane_b)));
+                    pr[u] = V<VEC>::template load_row<BF>(gb + (size_t)(o + lane_b));
                 }
             }
         };
@@ -446,7 +457,7 @@ agg_bwd_kernel(const BwdParams p) {
             V<VEC> acc = V<VEC>::zero();
             // (same pair walk as the forward: per-pair byte offsets are made once per fetched entry, the gather loop
             //  broadcasts them and adds the lane's column offset)
-            const char* gkb = reinterpret_cast<const char*>(p.g + (int64_t)k * p.g_sk);   // wave-uniform
+            const char* gkb = reinterpret_cast<const char*>(p.g) + (int64_t)k * p.g_sk * GB;   // wave-uniform
             if (CHUNKED) {
                 // (the prefetched rows are summed in place and their registers reused for the next prefetch: a copy would
                 //  wait for them just the same)
@@ -471,14 +482,14 @@ agg_bwd_kernel(const BwdParams p) {
                     for (; t + 1 < lim; t += 2) {
                         const int l0 = sg_lane0 + t, l1 = l0 + 1;
                         const uint32_t o0 = __shfl(coff, l0), o1 = __shfl(coff, l1);
-                        V<VEC> r0 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b)));
-                        V<VEC> r1 = V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o1 + lane_b)));
+                        V<VEC> r0 = V<VEC>::template load_row<BF>(gkb + (size_t)(o0 + lane_b));
+                        V<VEC> r1 = V<VEC>::template load_row<BF>(gkb + (size_t)(o1 + lane_b));
                         acc.add(r0);
                         acc.add(r1);
                     }
                     if (t < lim) {
                         const uint32_t o0 = __shfl(coff, sg_lane0 + t);
-                        acc.add(V<VEC>::load(reinterpret_cast<const float*>(gkb + (size_t)(o0 + lane_b))));
+                        acc.add(V<VEC>::template load_row<BF>(gkb + (size_t)(o0 + lane_b)));
                     }
                     pos = cbase + lim;
                 }
@@ -593,14 +604,14 @@ unsigned pick_grid(int64_t num_tiles, int blocks_per_cu) {
     return (unsigned)(g > 0 ? g : 1);
 }
 
-template <int VEC, int G, bool GCN, int TAB, bool FAST = false>
+template <int VEC, int G, bool GCN, int TAB, bool FAST = false, bool BF = false>
 int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, lds));
-    const int nb = resident_blocks(agg_fwd_kernel<VEC, G, GCN, TAB, FAST>, kBlock, lds);
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_fwd_kernel<VEC, G, GCN, TAB, FAST, BF>, lds));
+    const int nb = resident_blocks(agg_fwd_kernel<VEC, G, GCN, TAB, FAST, BF>, kBlock, lds);
     const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
-    hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB, FAST>), dim3(grid), dim3(kBlock), lds, s, p);
+    hipLaunchKernelGGL((agg_fwd_kernel<VEC, G, GCN, TAB, FAST, BF>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_fwd_kernel");
     return KPGNN_OK;
 }
@@ -608,25 +619,32 @@ int launch_fwd(const FwdParams& p, size_t lds, hipStream_t s) {
 template <int VEC, int G>
 int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
     const bool gcn = p.mode == KPGNN_MODE_GCN;
+    const bool fast = tab == 1 && p.mode == KPGNN_MODE_GINPLUS && p.combine && !p.periph && p.uid && p.ptab && p.pre;
+    if (p.bf) {     // bf16 rows: one instantiation family only (the KP-GIN+ training epilogue, 4 elements per lane)
+        if constexpr (VEC == 4) {
+            if (fast && !p.x) return launch_fwd<VEC, G, false, 1, true, true>(p, lds, s);
+        }
+        return fail(KPGNN_EINVAL, "aggregate_fwd: bf16 storage needs the fused KP-GIN+ epilogue (GELU, theta, dictionary P, "
+                    "code tables in LDS, S saved), per-hop inputs and D %% 4 == 0");
+    }
     switch (tab) {
         case 0: return gcn ? launch_fwd<VEC, G, true, 0>(p, 0, s) : launch_fwd<VEC, G, false, 0>(p, 0, s);
         case 1: {
             if (gcn) return launch_fwd<VEC, G, true, 1>(p, lds, s);
-            const bool fast = p.mode == KPGNN_MODE_GINPLUS && p.combine && !p.periph && p.uid && p.ptab && p.pre;
             return fast ? launch_fwd<VEC, G, false, 1, true>(p, lds, s) : launch_fwd<VEC, G, false, 1>(p, lds, s);
         }
         default: return gcn ? launch_fwd<VEC, G, true, 2>(p, 0, s) : launch_fwd<VEC, G, false, 2>(p, 0, s);
     }
 }
 
-template <int VEC, int G, bool GCN, int TAB>
+template <int VEC, int G, bool GCN, int TAB, bool BF = false>
 int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB>, lds));
-    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB>, kBlock, lds);
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB, BF>, lds));
+    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB, BF>, kBlock, lds);
     const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
-    hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB>), dim3(grid), dim3(kBlock), lds, s, p);
+    hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB, BF>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_bwd_kernel");
     return KPGNN_OK;
 }
@@ -634,6 +652,12 @@ int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
 template <int VEC, int G>
 int launch_bwd_mode(const BwdParams& p, int tab, size_t lds, hipStream_t s) {
     const bool gcn = p.mode == KPGNN_MODE_GCN;
+    if (p.bf) {     // bf16 rows of g: the atomics-free gather only (no GCN weights, no table grads, no GIN self term)
+        if constexpr (VEC == 4) {
+            if (!gcn && tab == 0 && p.mode != KPGNN_MODE_GIN) return launch_bwd<VEC, G, false, 0, true>(p, 0, s);
+        }
+        return fail(KPGNN_EINVAL, "aggregate_bwd: bf16 storage needs mode GINPLUS/SUM without table gradients and D %% 4 == 0");
+    }
     switch (tab) {
         case 0: return gcn ? launch_bwd<VEC, G, true, 0>(p, 0, s) : launch_bwd<VEC, G, false, 0>(p, 0, s);
         case 1: return gcn ? launch_bwd<VEC, G, true, 1>(p, lds, s) : launch_bwd<VEC, G, false, 1>(p, lds, s);
@@ -696,7 +720,8 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         if (pt_b && lds + pt_b <= cap) { p.lds_ptab = d->n_dict * d->D; lds += (pt_b + 15) & ~(size_t)15; }
     }
     p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
-    p.mode = d->mode; p.combine = combine ? 1 : 0;
+    p.mode = d->mode; p.combine = combine ? 1 : 0; p.bf = d->storage == KPGNN_STORE_BF16 ? 1 : 0;
+    KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "aggregate_fwd: unknown storage %d", d->storage);
     p.rowptr = d->rowptr; p.col = d->col; p.code = d->code; p.dis = d->dis;
     p.x = d->x; p.x_sn = d->x_sn; p.x_sk = d->x_sk;
     p.table0 = d->table0; p.tablek = d->tablek;
@@ -755,7 +780,8 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
     }
     BwdParams p;
     p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
-    p.mode = d->mode;
+    p.mode = d->mode; p.bf = d->storage == KPGNN_STORE_BF16 ? 1 : 0;
+    KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "aggregate_bwd: unknown storage %d", d->storage);
     p.rowptr = d->rowptr_src; p.col = d->col_src; p.code = d->code_src; p.dis = d->dis;
     p.g = d->g; p.g_sn = d->g_sn; p.g_sk = d->g_sk; p.eps = d->eps;
     p.gx = d->gx; p.gx_sn = d->gx_sn; p.gx_sk = d->gx_sk; p.gtable0 = d->gtable0; p.gtablek = d->gtablek;

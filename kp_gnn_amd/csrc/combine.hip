@@ -45,6 +45,7 @@ struct CbParams {
     float* gv;
     float* slab;     // [gridDim.x][K][D] theta-gradient partials, or NULL
     int lds_ptab;    // floats of ptab staged in LDS (0: read from global)
+    int bf;          // pre and g are bf16 rows
 };
 
 // Row streaming: a sub-group of G lanes owns one (node, hop) ROW of S per step and strides over the rows; the grid
@@ -55,7 +56,8 @@ struct CbParams {
 // ACT: 1 = GELU (KP-GIN+), 2 = ReLU (KP-GCN), 0 = none; WGT: theta gradient wanted.  Compile-time so that the
 // per-element arithmetic is straight-line code (as runtime switches it was a chain of uniform branches per element
 // that kept the VALU from overlapping the four rows in flight).
-template <int VEC, int G, int ACT, bool WGT>
+// BF: `pre` and `g` are bf16 rows (2 bytes per element); the arithmetic and every other operand stay fp32.
+template <int VEC, int G, int ACT, bool WGT, bool BF = false>
 __global__ void __launch_bounds__(kBlock)
 combine_bwd_kernel(const CbParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [lds_ptab] dictionary rows, then [NODES][D] reduction
@@ -96,7 +98,8 @@ combine_bwd_kernel(const CbParams p) {
                 for (int q = 0; q < VEC; ++q) { s[u][q] = 0.f; gvv[u][q] = 0.f; ghv[u][q] = 0.f; pv[u][q] = 0.f; }
                 u_id[u] = -1;
                 if (ru < R) {
-                    ldv_stream<VEC>(pre + ru * D + c0, s[u]);
+                    if (BF) ld_bf16_stream<VEC>(reinterpret_cast<const uint16_t*>(pre) + ru * D + c0, s[u]);
+                    else ldv_stream<VEC>(pre + ru * D + c0, s[u]);
                     if (fused) ldv<VEC>(p.gh + iu * D + c0, ghv[u]);
                     else ldv<VEC>(p.gout + iu * p.go_sn + (int64_t)k * p.go_sk + c0, gvv[u]);
                     if (want_gt) {
@@ -127,7 +130,8 @@ combine_bwd_kernel(const CbParams p) {
                         gg[q] = gvv[u][q];
                     }
                 }
-                stv<VEC>(gout_p + ru * D + c0, gg);
+                if (BF) st_bf16<VEC>(reinterpret_cast<uint16_t*>(gout_p) + ru * D + c0, gg);
+                else stv<VEC>(gout_p + ru * D + c0, gg);
                 if (p.gv) stv<VEC>(p.gv + ru * D + c0, gvv[u]);
                 if (want_gt) {
                     if (u_id[u] >= 0) ldv<VEC>(ptp + (int64_t)u_id[u] * D + c0, pv[u]);
@@ -186,13 +190,13 @@ int cb_shape(const kpgnn_combine_bwd_desc* d, int* vec, int* g) {
     return KPGNN_OK;
 }
 
-template <int VEC, int G, int ACT, bool WGT>
+template <int VEC, int G, int ACT, bool WGT, bool BF = false>
 int cb_launch2(const CbParams& p, int* grid_out, size_t lds, hipStream_t s) {
-    if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, ACT, WGT>, lds));
+    if (lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)combine_bwd_kernel<VEC, G, ACT, WGT, BF>, lds));
     // grid-stride kernel: one resident round (kpgnn_common.h, resident_blocks)
-    const int grid = cb_grid(p.N, p.K, G, resident_blocks(combine_bwd_kernel<VEC, G, ACT, WGT>, kBlock, lds));
+    const int grid = cb_grid(p.N, p.K, G, resident_blocks(combine_bwd_kernel<VEC, G, ACT, WGT, BF>, kBlock, lds));
     *grid_out = grid;
-    hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, ACT, WGT>), dim3(grid), dim3(kBlock), lds, s, p);
+    hipLaunchKernelGGL((combine_bwd_kernel<VEC, G, ACT, WGT, BF>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("combine_bwd_kernel");
     return KPGNN_OK;
 }
@@ -201,6 +205,12 @@ template <int VEC, int G>
 int cb_launch(const CbParams& p, int* grid, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)(((p.lds_ptab + 3) & ~3) + (p.slab ? (kBlock / G) * p.D : 0));
     const int act = p.mode == KPGNN_MODE_GINPLUS ? 1 : (p.mode == KPGNN_MODE_GCN ? 2 : 0);
+    if (p.bf) {     // bf16 rows: the KP-GIN+ epilogue, 4 elements per lane
+        if constexpr (VEC == 4) {
+            if (act == 1 && !p.gv) return p.slab ? cb_launch2<VEC, G, 1, true, true>(p, grid, lds, s) : cb_launch2<VEC, G, 1, false, true>(p, grid, lds, s);
+        }
+        return fail(KPGNN_EINVAL, "combine_bwd: bf16 storage needs mode GINPLUS, no gv and D %% 4 == 0");
+    }
     if (p.slab) {
         if (act == 1) return cb_launch2<VEC, G, 1, true>(p, grid, lds, s);
         if (act == 2) return cb_launch2<VEC, G, 2, true>(p, grid, lds, s);
@@ -237,7 +247,8 @@ extern "C" int kpgnn_combine_bwd(const kpgnn_combine_bwd_desc* d, kpgnn_stream_t
     p.N = d->N; p.K = d->K; p.D = d->D; p.mode = d->mode; p.pre = d->pre; p.gh = d->gh; p.theta = d->theta;
     p.gout = d->gout; p.go_sn = d->go_sn; p.go_sk = d->go_sk; p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
-    p.g = d->g; p.gv = d->gv; p.slab = nullptr;
+    p.g = d->g; p.gv = d->gv; p.slab = nullptr; p.bf = d->storage == KPGNN_STORE_BF16 ? 1 : 0;
+    KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "combine_bwd: unknown storage %d", d->storage);
     int grid = cb_grid(d->N, d->K, g, 8);           // upper bound (workspace check); the launcher picks the real one
     p.lds_ptab = 0;
     if (d->gtheta) {

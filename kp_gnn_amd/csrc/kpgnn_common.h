@@ -89,6 +89,59 @@ __device__ __forceinline__ float fast_erf(float z, float* e2_out) {
     return copysignf(fmaf(-poly * t, e2, 1.0f), z);
 }
 
+// bf16 STORAGE of rows that are otherwise fp32 (kpgnn.h: `storage` = KPGNN_STORE_BF16): the value is the upper half of the
+// fp32 pattern, rounded to nearest even on the way out; every sum stays fp32.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;      // (inf stays inf; a NaN stays a NaN unless its payload is only low bits)
+}
+template <int VEC> __device__ __forceinline__ void ld_bf16(const void* q, float (&v)[VEC]) {
+    if (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(q);
+        v[0] = __uint_as_float(t.x << 16); v[1 % VEC] = __uint_as_float(t.x & 0xFFFF0000u);
+        v[2 % VEC] = __uint_as_float(t.y << 16); v[3 % VEC] = __uint_as_float(t.y & 0xFFFF0000u);
+    } else if (VEC == 2) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(q);
+        v[0] = __uint_as_float(t << 16); v[1 % VEC] = __uint_as_float(t & 0xFFFF0000u);
+    } else {
+        v[0] = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(q) << 16);
+    }
+}
+// streaming forms (nt): rows nobody re-reads in this launch should not displace the gathered rows in L2
+template <int VEC> __device__ __forceinline__ void ld_bf16_stream(const void* q, float (&v)[VEC]) {
+    if (VEC == 4) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+        const uint32_t x = __builtin_nontemporal_load(w), y = __builtin_nontemporal_load(w + 1);
+        v[0] = __uint_as_float(x << 16); v[1 % VEC] = __uint_as_float(x & 0xFFFF0000u);
+        v[2 % VEC] = __uint_as_float(y << 16); v[3 % VEC] = __uint_as_float(y & 0xFFFF0000u);
+    } else {
+        ld_bf16<VEC>(q, v);
+    }
+}
+template <int VEC> __device__ __forceinline__ void st_bf16_stream(void* q, const float (&v)[VEC]) {
+    if (VEC == 4) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(q);
+        __builtin_nontemporal_store(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1 % VEC]) << 16), w);
+        __builtin_nontemporal_store(f32_to_bf16_bits(v[2 % VEC]) | (f32_to_bf16_bits(v[3 % VEC]) << 16), w + 1);
+    } else if (VEC == 2) {
+        __builtin_nontemporal_store(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1 % VEC]) << 16), reinterpret_cast<uint32_t*>(q));
+    } else {
+        *reinterpret_cast<uint16_t*>(q) = (uint16_t)f32_to_bf16_bits(v[0]);
+    }
+}
+template <int VEC> __device__ __forceinline__ void st_bf16(void* q, const float (&v)[VEC]) {
+    if (VEC == 4) {
+        uint2 t;
+        t.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1 % VEC]) << 16);
+        t.y = f32_to_bf16_bits(v[2 % VEC]) | (f32_to_bf16_bits(v[3 % VEC]) << 16);
+        *reinterpret_cast<uint2*>(q) = t;
+    } else if (VEC == 2) {
+        *reinterpret_cast<uint32_t*>(q) = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1 % VEC]) << 16);
+    } else {
+        *reinterpret_cast<uint16_t*>(q) = (uint16_t)f32_to_bf16_bits(v[0]);
+    }
+}
+
 // XCD-aware tile order.  Blocks b and b+8 share an XCD (own L2).  The tile range is cut into 8
 // contiguous slabs, one per XCD, and the blocks of one XCD walk their slab tile by tile, so that
 // the rows a slab's graphs gather stay inside one 4 MiB L2.  Placement only affects speed.

@@ -63,7 +63,8 @@ template <> struct Cols<2> {
 
 // LDS (floats): tile [NT*K*D] | acc [(R + kSlotRows)][AS] | ghs [NT][AS] | ths [8][AS] | meta [2*kWavesTG] (uint32)
 // AS = the block's column count (gridDim.y == 1: D).  acc rows R.. are the first-run slots.
-template <int CPL, bool VEC4>
+// BF: g holds bf16 rows (KPGNN_STORE_BF16); they are widened on the way into the LDS tile, everything behind is fp32.
+template <int CPL, bool VEC4, bool BF = false>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // (HIP: waves per SIMD) two blocks per CU: 128 VGPRs
 table_grad_kernel(const TgParams p, int AS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -90,15 +91,35 @@ table_grad_kernel(const TgParams p, int AS) {
         }
     const int64_t num_tiles = ((int64_t)p.N + p.NT - 1) / p.NT;
     const int64_t total = (int64_t)p.N * K * D;
-    constexpr int kPref = 4;
+    // 16 bytes per thread and request: 4 floats, or 8 bf16 (VEC4 then means "K*D % 8 == 0")
+    constexpr int kPref = BF ? 2 : 4;
+    constexpr int EPL = BF ? 8 : 4;                  // elements per 16-byte load
+    const uint16_t* gbf = reinterpret_cast<const uint16_t*>(p.g);
     float4 pref[kPref];
+    auto load16 = [&](int64_t i) -> float4 {
+        return BF ? *reinterpret_cast<const float4*>(gbf + i) : *reinterpret_cast<const float4*>(p.g + i);
+    };
+    auto store16 = [&](float* dst, const float4& v) {         // one 16-byte load's worth into the fp32 tile
+        if (BF) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+            float4 lo, hi;
+            lo.x = __uint_as_float(w[0] << 16); lo.y = __uint_as_float(w[0] & 0xFFFF0000u);
+            lo.z = __uint_as_float(w[1] << 16); lo.w = __uint_as_float(w[1] & 0xFFFF0000u);
+            hi.x = __uint_as_float(w[2] << 16); hi.y = __uint_as_float(w[2] & 0xFFFF0000u);
+            hi.z = __uint_as_float(w[3] << 16); hi.w = __uint_as_float(w[3] & 0xFFFF0000u);
+            *reinterpret_cast<float4*>(dst) = lo;
+            *reinterpret_cast<float4*>(dst + 4) = hi;
+        } else {
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    };
     if (VEC4) {
 #pragma unroll
         for (int q = 0; q < kPref; ++q) {
-            const int64_t i = (int64_t)blockIdx.x * tile_floats + (q * kThreadsTG + threadIdx.x) * 4;
+            const int64_t i = (int64_t)blockIdx.x * tile_floats + (q * kThreadsTG + threadIdx.x) * EPL;
             pref[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (blockIdx.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * 4 < tile_floats)
-                pref[q] = *reinterpret_cast<const float4*>(p.g + i);
+            if (blockIdx.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * EPL < tile_floats)
+                pref[q] = load16(i);
         }
     }
     // Per-tile metadata travels ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the window
@@ -216,20 +237,21 @@ table_grad_kernel(const TgParams p, int AS) {
             // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
             for (int q = 0; q < kPref; ++q) {
-                const int i = (q * kThreadsTG + threadIdx.x) * 4;
-                if (i < nfl) *reinterpret_cast<float4*>(tile + i) = pref[q];
+                const int i = (q * kThreadsTG + threadIdx.x) * EPL;
+                if (i < nfl) store16(tile + i, pref[q]);
             }
-            for (int i = (kPref * kThreadsTG + threadIdx.x) * 4; i < nfl; i += kThreadsTG * 4)
-                *reinterpret_cast<float4*>(tile + i) = *reinterpret_cast<const float4*>(p.g + base + i);
+            for (int i = (kPref * kThreadsTG + threadIdx.x) * EPL; i < nfl; i += kThreadsTG * EPL)
+                store16(tile + i, load16(base + i));
             const int64_t nb = base + (int64_t)gridDim.x * tile_floats;
 #pragma unroll
             for (int q = 0; q < kPref; ++q) {
-                const int64_t i = nb + (q * kThreadsTG + threadIdx.x) * 4;
-                if (tl + gridDim.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * 4 < tile_floats)
-                    pref[q] = *reinterpret_cast<const float4*>(p.g + i);
+                const int64_t i = nb + (q * kThreadsTG + threadIdx.x) * EPL;
+                if (tl + gridDim.x < num_tiles && i < total && (q * kThreadsTG + threadIdx.x) * EPL < tile_floats)
+                    pref[q] = load16(i);
             }
         } else {
-            for (int i = threadIdx.x; i < nfl; i += kThreadsTG) tile[i] = p.g[base + i];
+            for (int i = threadIdx.x; i < nfl; i += kThreadsTG)
+                tile[i] = BF ? __uint_as_float((uint32_t)gbf[base + i] << 16) : p.g[base + i];
         }
         if (p.dict_src == 1 && w < p.NT && col_ok) ghv.store(ghs + w * AS + cc);
         __syncthreads();
@@ -489,10 +511,10 @@ int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     return KPGNN_OK;
 }
 
-template <int CPL, bool VEC4>
+template <int CPL, bool VEC4, bool BF = false>
 int launch_walk(const TgParams& p, const Plan& pl, hipStream_t s) {
-    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4>, pl.lds));
-    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4, BF>, pl.lds));
+    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4, BF>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
     KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return KPGNN_OK;
 }
@@ -546,7 +568,8 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
         // dictionary rows) at D = 13.  Wide rows stay on the register walk (the 16x16x4 product is matrix-core bound
         // there).  d->kernel = 1 / 2 forces one of them (the parity tests compare the two).
-        const int force = d->kernel;
+        KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "table_grad: unknown storage %d", d->storage);
+        const int force = d->storage == KPGNN_STORE_BF16 ? 1 : d->kernel;    // (bf16 rows: the walk kernel only)
         // (the walk adds finished runs with plain read-modify-writes: it needs BOTH lists sorted by row)
         const bool walk_fits = d->K <= 8 && d->nodes_per_tile * d->K <= kMaxRows && (d->n_dict == 0 || d->dict_pack);
         KPGNN_REQUIRE(force != 1 || walk_fits, "table_grad: the walk kernel needs K <= 8, tiles of <= 64 (node, hop) rows and, "
@@ -576,8 +599,12 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     p.slab = (float*)d->workspace;
     // the tile copy is flat: 16-B loads only need every node's K*D floats to be a multiple of 4
-    const bool vec4 = (((int64_t)p.K * p.D) % 4 == 0) && (((uintptr_t)p.g & 15) == 0);
-    if (pl.cpl == 2) rc = vec4 ? launch_walk<2, true>(p, pl, s) : launch_walk<2, false>(p, pl, s);
+    const bool bf = d->storage == KPGNN_STORE_BF16;
+    const bool vec4 = (((int64_t)p.K * p.D) % (bf ? 8 : 4) == 0) && (((uintptr_t)p.g & 15) == 0);
+    if (bf) {
+        KPGNN_REQUIRE(pl.cpl == 2, "table_grad: bf16 storage needs an even D");
+        rc = vec4 ? launch_walk<2, true, true>(p, pl, s) : launch_walk<2, false, true>(p, pl, s);
+    } else if (pl.cpl == 2) rc = vec4 ? launch_walk<2, true>(p, pl, s) : launch_walk<2, false>(p, pl, s);
     else rc = vec4 ? launch_walk<1, true>(p, pl, s) : launch_walk<1, false>(p, pl, s);
     if (rc != KPGNN_OK) return rc;
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,

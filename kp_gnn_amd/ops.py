@@ -44,12 +44,41 @@ def set_launch_timer(timer):
     _timer = timer
 
 
-def algorithmic_bytes(csr, k_act, D, n_tensors, n_rows_tables, extra_nd=0):
+def algorithmic_bytes(csr, k_act, D, n_tensors, n_rows_tables, extra_nd=0, s=4):
     """s*N*k*D per streamed [N,k,D] tensor + (4+2) B per active pair + int32 row pointers
-    + the tables once (+ s*N*D per [N,D] tensor), s = 4 (fp32)."""
+    + the tables once (+ 4*N*D per fp32 [N,D] tensor), s = 4 (fp32) or 2 (bf16 storage).  n_tensors may be fractional
+    when the streams of one launch have different widths (it counts fp32-equivalents at s = 4)."""
     A = csr.active_pairs(k_act)
-    return 4 * csr.N * k_act * D * n_tensors + A * 6 + 4 * (csr.N * csr.K + 1) + 4 * D * n_rows_tables \
+    return int(s * csr.N * k_act * D * n_tensors) + A * 6 + 4 * (csr.N * csr.K + 1) + 4 * D * n_rows_tables \
         + 4 * csr.N * D * extra_nd
+
+
+# Storage of the big per-(node,hop) streams of the fused KP-GIN+ path (hop-slot rows, S saved for the backward, dL/dS):
+# torch.float32 (default) or torch.bfloat16 (kpgnn.h KPGNN_STORE_BF16: 2-byte rows, fp32 sums).  Other paths ignore it.
+_STORAGE = torch.float32
+
+
+def set_storage_dtype(dtype):
+    """torch.float32 / torch.bfloat16 (or "fp32" / "bf16"): see _STORAGE.  Returns the previous setting."""
+    global _STORAGE
+    prev = _STORAGE
+    dtype = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}.get(dtype, dtype)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"storage dtype must be float32 or bfloat16, got {dtype}")
+    _STORAGE = dtype
+    return prev
+
+
+def bf16_shadow(t):
+    """bf16 copy of a hop state [N,D] for the gathers of later layers (made once per state, kept on the tensor)."""
+    sh = getattr(t, "_kp_bf16", None)
+    if sh is None:
+        sh = t.detach().to(torch.bfloat16).contiguous()
+        try:
+            t._kp_bf16 = sh
+        except AttributeError:
+            pass
+    return sh
 
 
 def _ptr(t):
@@ -104,8 +133,9 @@ class DictPeripheral:
 
 
 def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, want_pre, ptab=None, uid=None,
-                      xs=None, alphas=None):
+                      xs=None, alphas=None, bf16=False):
     """Launch kpgnn_aggregate_fwd.  x is [N,k,D], or None with xs = k per-hop [N,D] tensors (row stride shared).
+    bf16: xs are bf16 rows and `pre` is returned as bf16 (KPGNN_STORE_BF16).
     Returns (out or hout, pre or None)."""
     lib = _lib.load()
     if x is not None:
@@ -138,8 +168,9 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.n_dict = ptab.shape[0]
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
-    pre = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_pre else None
+    pre = torch.empty((N, K, D), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev) if want_pre else None
     d.pre = _ptr(pre)
+    d.storage = 1 if bf16 else 0
     if theta is not None:
         out = torch.empty((N, D), dtype=torch.float32, device=dev)
         d.theta, d.hout = theta.data_ptr(), out.data_ptr()
@@ -157,7 +188,8 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
             n_t = 1 + (periph is not None) + (pre is not None) + (theta is None)  # x, dense P, pre, out
             extra = 4 * N * K if uid is not None else 0                           # int32 uid per (node,hop)
             _timer.records.append(("agg_fwd", extra + algorithmic_bytes(csr, K, D, n_t, d.n_code0 + d.n_codek,
-                                                                        extra_nd=1 if theta is not None else 0), e0, e1))
+                                                                        extra_nd=1 if theta is not None else 0,
+                                                                        s=2 if bf16 else 4), e0, e1))
     return out, pre
 
 
@@ -168,8 +200,10 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     lib = _lib.load()
     N, K, D = g.shape
     dev = g.device
+    bf16 = g.dtype == torch.bfloat16      # KPGNN_STORE_BF16: g rows are bf16, gx stays fp32
     d = _lib.AggBwdDesc()
     d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
+    d.storage = 1 if bf16 else 0
     d.use_tables = 1 if want_tables else 0
     d.n_code0, d.n_codek = n_code0, n_codek
     d.rowptr_src, d.col_src, d.code_src = csr.rowptr_src.data_ptr(), csr.col_src.data_ptr(), csr.code_src.data_ptr()
@@ -218,8 +252,9 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
         _lib.check(lib.kpgnn_aggregate_bwd(ctypes.byref(d), _stream(g)), "kpgnn_aggregate_bwd")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 2, (n_code0 + n_codek) if want_tables else 0),
-                                   e0, e1))
+            # g read (2 or 4 bytes per element) + gx written (fp32)
+            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 1.5 if bf16 else 2,
+                                                                (n_code0 + n_codek) if want_tables else 0), e0, e1))
     for k, b in late_adds:
         gx[k] = b.add_(gx[k])
     return gx, gt0, gtk
@@ -299,6 +334,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     d.n_dict = n_dict
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
     d.kernel = kernel
+    d.storage = 1 if g.dtype == torch.bfloat16 else 0
     if edges:
         tptr, tpack = csr.tile_list(K)          # (hop-prefix copy of the entry list when this layer sees K < csr.K hops)
         d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
@@ -327,7 +363,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(g)), "kpgnn_table_grad")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("table_grad", 4 * N * K * D + (4 * csr.active_pairs(K) if edges else 0)
+            _timer.records.append(("table_grad", g.element_size() * N * K * D + (4 * csr.active_pairs(K) if edges else 0)
                                    + 4 * D * (n0 + nk + n_dict) + (4 * N * K if n_dict else 0), e0, e1))
     return gt0, gtk, gd
 
@@ -350,7 +386,9 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
     elif uid is not None and ptab is not None:  # (P is only read for the theta gradient)
         d.ptab, d.uid, d.uid_stride = ptab.data_ptr(), uid.data_ptr(), uid.stride(0)
         d.n_dict = ptab.shape[0]
-    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    bf16 = pre.dtype == torch.bfloat16    # KPGNN_STORE_BF16: S arrives and dL/dS leaves as bf16 rows
+    d.storage = 1 if bf16 else 0
+    g = torch.empty((N, K, D), dtype=pre.dtype, device=dev)
     gv = torch.empty((N, K, D), dtype=torch.float32, device=dev) if want_gv else None
     gth = torch.empty((K, D), dtype=torch.float32, device=dev) if want_gtheta else None
     d.g, d.gv, d.gtheta = g.data_ptr(), _ptr(gv), _ptr(gth)
@@ -370,7 +408,7 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
         if _timer is not None:
             e1.record()
             n_t = 2 + (gv is not None) + (theta is None) + (periph is not None and want_gtheta)
-            _timer.records.append(("combine_bwd", 4 * N * K * D * n_t + (4 * N * D if theta is not None else 0), e0, e1))
+            _timer.records.append(("combine_bwd", (2 if bf16 else 4) * N * K * D * n_t + (4 * N * D if theta is not None else 0), e0, e1))
     if gal is not None:
         return g, gv, (gth, gal)
     return g, gv, gth
@@ -392,9 +430,14 @@ class KHopAggregate(torch.autograd.Function):
         ctx.cells = cells
         _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
         ctx.n_slots = len(xs)
+        bf16 = False
         if xs:   # per-hop inputs: k separate [N,D] states instead of one stacked [N,k,D] tensor
             assert x is None and len(xs) == k_act
-            xs = [t.float() for t in xs]
+            # bf16 storage (set_storage_dtype): only the configuration the bf16 kernels exist for - the fused KP-GIN+
+            # epilogue with a dictionary P and code tables; everything else stays fp32
+            bf16 = (_STORAGE is torch.bfloat16 and mode == MODE_GINPLUS and theta is not None and ptab is not None
+                    and periph is None and table0 is not None and xs[0].shape[1] % 8 == 0 and eps is None)
+            xs = [bf16_shadow(t) if bf16 else t.float() for t in xs]
             # the kernel reads every hop slot with ONE row stride (x_sn): row-strided slots (column slices of the bodies'
             # jumping-knowledge buffer) are read where they are; only mixed layouts are copied
             if any(t.stride(1) != 1 for t in xs) or len({t.stride(0) for t in xs}) != 1:
@@ -419,7 +462,7 @@ class KHopAggregate(torch.autograd.Function):
             ptab = ptab.contiguous()
         need_pre = mode in (MODE_GINPLUS, MODE_GCN) or theta is not None
         out, pre = aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, xbias, need_pre,
-                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None, alphas=alphas)
+                                     ptab=ptab, uid=uid, xs=list(xs) if xs else None, alphas=alphas, bf16=bf16)
         ctx.alphas = alphas
         ctx.csr, ctx.k_act, ctx.mode, ctx.uid = csr, k_act, mode, uid
         ctx.has_tables = table0 is not None
