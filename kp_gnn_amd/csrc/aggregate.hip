@@ -709,6 +709,11 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));
         tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
     }
+    {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
+        bool handled = false;
+        const int rc = agg_narrow_fwd(d, (hipStream_t)stream, &handled);
+        if (rc != KPGNN_OK || handled) return rc;
+    }
     FwdParams p;
     p.lds_theta = p.lds_ptab = 0;
     if (tab == 1) {      // small side tables behind the code tables (keeps >= 4 blocks of 256 threads per CU)
@@ -777,6 +782,11 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->n_code0 >= 1 && (d->K == 1 || (d->gtablek && d->n_codek >= 1)), "aggregate_bwd: missing table grads");
         lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));
         tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
+    }
+    {   // narrow rows: the element-per-thread gather (aggregate_narrow.hip)
+        bool handled = false;
+        const int rc = agg_narrow_bwd(d, (hipStream_t)stream, &handled);
+        if (rc != KPGNN_OK || handled) return rc;
     }
     BwdParams p;
     p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
