@@ -8,8 +8,8 @@
 // (row pointer -> pair -> row) whatever K is, consecutive lanes read consecutive floats of the same 52-byte row (one
 // request) and the same pair-list entry (a broadcast).  Pairs are added in list order, as the reference's
 // index_add_ over edges does (KPGIN.py:96-105) - results do not depend on the kernel choice.
-// Measured (round 2): it wins where a launch is latency-bound - 3-regular n = 1280, 582 pairs per node, batch 1: 32 us
-// against 250; QM9-shaped batch 128: 11 us against 25 - and loses where the sub-group kernels' prefetch across hops keeps
+// Measured (round 2): it wins where a launch is latency-bound - 3-regular n = 1280, 582 pairs per node, batch 1: 31 us
+// against 239; QM9-shaped batch 128: 11 us against 33 - and loses where the sub-group kernels' prefetch across hops keeps
 // more rows in flight per wave: ZINC batch 2048 (N = 47k, D = 13) 64 us against 47, regular batch 100 1.34 ms against 0.95.
 // Four elements per thread did not help (84 us: registers, divergence).  Hence kNarrowMaxElems below.
 #include "kpgnn_common.h"

@@ -8,6 +8,7 @@ run bench_default
 run bench_b64 --batch 64 --steps 100
 run bench_kpgin --model KPGIN --cpu-graphs 64
 run bench_attention --combine attention --cpu-graphs 64
+run bench_bf16 --dtype bf16 --no-cpu-baseline
 run bench_dense_peripheral --dense-peripheral --no-cpu-baseline
 run bench_qm9 --workload qm9 --cpu-graphs 64
 run bench_regular_b1 --workload regular --batch 1 --steps 50
@@ -19,6 +20,7 @@ prof default --steps 20 --warmup 3
 prof b64 --batch 64 --steps 50 --warmup 3
 prof kpgin --model KPGIN --steps 20 --warmup 3
 prof attention --combine attention --steps 20 --warmup 3
+prof bf16 --dtype bf16 --steps 20 --warmup 3
 prof zinc_gd16 --workload zinc_gd16 --batch 512 --steps 20 --warmup 3
 prof qm9 --workload qm9 --steps 50 --warmup 3
 prof regular_b1 --workload regular --batch 1 --steps 50 --warmup 3
@@ -30,9 +32,11 @@ pmc sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES
 pmc sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_ANY
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 cd $GRAFT_REPO_ROOT
-for n in default b64 kpgin attention zinc_gd16 qm9 regular_b1 dense_peripheral; do python scripts/kstats.py $R/prof_$n 40 > $R/kstats_$n.txt 2>&1; done
+for n in default b64 kpgin attention bf16 zinc_gd16 qm9 regular_b1 dense_peripheral; do python scripts/kstats.py $R/prof_$n 40 > $R/kstats_$n.txt 2>&1; done
 DIG=$(python -c "import bench; print(bench.csrc_digest())")
 python scripts/pmc_summarize.py traffic $R/pmc_fetch $R/pmc_write $R/pmc_traffic.json "zinc|KPGINPlus|B2048|K8|L8|h104|geometric" $DIG > /dev/null 2>&1; echo "traffic rc=$?"
+# the headline line again, now that the traffic figure of THESE sources exists (bench.py reads profiles/r02/pmc_traffic.json)
+mkdir -p profiles/r02 && cp $R/pmc_traffic.json profiles/r02/pmc_traffic.json && run bench_default
 python scripts/pmc_summarize.py sq $R/pmc_sq1 $R/pmc_sq1.json > /dev/null 2>&1; python scripts/pmc_summarize.py sq $R/pmc_sq2 $R/pmc_sq2.json > /dev/null 2>&1
 python scripts/pmc_summarize.py mfma $R/pmc_mfma $R/pmc_mfma.json > /dev/null 2>&1
 find $R -name "*agent_info.csv" -delete; find $R -name "*kernel_trace.csv" -size +20M -delete
