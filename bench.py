@@ -159,6 +159,22 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def stream_copy_gbps(device):
+    """What a plain device-to-device copy of a [N,8,104]-sized fp32 tensor reaches on this GPU (read + write bytes over HIP-event
+    time): the practical ceiling next to the nominal 8 TB/s of the roofline."""
+    x = torch.empty(47450 * 8 * 104, dtype=torch.float32, device=device).normal_()
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * x.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the PMC counters.  A process cannot profile itself, so the figure comes
     from the committed rocprofv3 --pmc passes of this same command (profiles/r02/pmc_traffic.json says how they were
@@ -391,6 +407,7 @@ def main():
                                    "traffic": None, "launches": f["launches"], "avg_launch_ms": round(f["avg_ms"], 4),
                                    "algorithmic_bytes_per_launch": int(f["bytes_per_launch"])}
                 out["roofline"].update(pmc_traffic(args, "agg_fwd_kernel"))
+                out["roofline"]["measured_copy_GBps"] = round(stream_copy_gbps(device), 1)
             out["kernels"] = {k: {"launches": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                                   "algorithmic_GBps": round(v["gbps"], 1)} for k, v in s.items()}
             big = [r for r in timer.records if r[0] == "agg_fwd"]

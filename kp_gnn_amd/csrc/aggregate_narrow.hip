@@ -18,7 +18,7 @@ namespace kpgnn {
 namespace {
 
 constexpr int kBlockN = 256;
-constexpr int64_t kNarrowMaxElems = 1 << 20;   // N*K*D up to which this kernel is used (see the header)
+constexpr int64_t kNarrowMaxElems = 1 << 21;   // N*K*D up to which this kernel is used (see the header)
 
 struct NarrowParams {
     int N, K, D, K_csr, n_code0, n_codek, mode;
