@@ -238,11 +238,28 @@ typedef struct kpgnn_table_grad_desc {
     int64_t extra_elems;
     float* extra_out;
     int32_t storage;            /* KPGNN_STORE_*: with BF16, g (storage) holds bf16 rows (walk kernel, D % 8 == 0) */
+    /* Fused combine backward (fuse_pre != NULL; KP-GIN+ epilogue, fp32, edge tables only, K <= 8, even D <= 128): the
+     * launch COMPUTES g = theta[k] * gh[i] * gelu'(S[i,k]) per tile (kpgnn_combine_bwd's arithmetic), writes it to fuse_g
+     * and walks it from LDS - `g` above is not read.  fuse_gtheta [K,D] (optional) = sum_i gh[i] * (gelu(S[i,k]) + P[i,k]) with
+     * P from the dictionary (fuse_ptab, fuse_uid; NULL = no P); with fuse_alphas / fuse_galphas the finishing launch also
+     * differentiates theta(alphas) as kpgnn_combine_bwd does.  fuse_workspace >= kpgnn_table_grad_fuse_workspace_bytes(K, D). */
+    const float* fuse_pre;      /* device [N,K,D] contiguous: S saved by the forward */
+    const float* fuse_ptab;     /* device [fuse_n_dict, D] */
+    const int32_t* fuse_uid;    /* device [N, fuse_uid_stride] */
+    int64_t fuse_uid_stride;
+    int32_t fuse_n_dict;
+    float* fuse_g;              /* device [N,K,D] contiguous (written) */
+    float* fuse_gtheta;         /* device [K,D] or NULL */
+    const float* fuse_alphas;   /* device [D] or NULL */
+    float* fuse_galphas;        /* device [D] or NULL */
+    void* fuse_workspace;
+    size_t fuse_workspace_bytes;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
                                         int32_t n_code0, int32_t n_codek, int32_t n_dict);
 int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t stream);
+size_t kpgnn_table_grad_fuse_workspace_bytes(int32_t K, int32_t D);
 /* pack[tile*64 + j] = uid<<8 | node_in_tile<<3 | hop for the (node, hop) entries of a tile of nodes_per_tile nodes
  * (nodes_per_tile * K <= 64, K <= 8), sorted by uid; unused places hold 0xFFFFFFFF.  pack: uint32[ceil(N/npt) * 64].
  * A one-off per batch (the ids are data): the reference recomputes nothing like it - its embedding backward sorts the

@@ -56,6 +56,9 @@ class TableGradDesc(ctypes.Structure):
         ("kernel", c_i32),
         ("dict_pack", c_vp), ("dict_pack_K", c_i32),
         ("extra_slab", c_vp), ("extra_nslab", c_i32), ("extra_elems", c_i64), ("extra_out", c_vp), ("storage", c_i32),
+        ("fuse_pre", c_vp), ("fuse_ptab", c_vp), ("fuse_uid", c_vp), ("fuse_uid_stride", c_i64), ("fuse_n_dict", c_i32),
+        ("fuse_g", c_vp), ("fuse_gtheta", c_vp), ("fuse_alphas", c_vp), ("fuse_galphas", c_vp),
+        ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -192,6 +195,7 @@ SIGNATURES = {
     "kpgnn_aggregate_bwd": (ctypes.c_int, [ctypes.POINTER(AggBwdDesc), c_vp]),
     "kpgnn_table_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 7),
     "kpgnn_table_grad": (ctypes.c_int, [ctypes.POINTER(TableGradDesc), c_vp]),
+    "kpgnn_table_grad_fuse_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "kpgnn_dict_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 4),
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),

@@ -39,7 +39,19 @@ struct TgParams {
     const float* theta;
     const float* gh;
     float* slab;             // [gridDim.x][n0 + nk + U][D]
+    // FUSE (combine backward computed here instead of read from g): S, the dictionary for the theta gradient, outputs
+    const float* f_pre;      // [N,K,D] S saved by the forward
+    const float* f_ptab; const int32_t* f_uid; int64_t f_uid_stride; int f_U;   // P = ptab[uid] (theta gradient only)
+    float* f_g;              // [N,K,D] dL/dS out
+    float* f_gth;            // [gridDim.x][K][D] theta-gradient partials, or NULL
 };
+
+__device__ __forceinline__ void gelu_bwd2(float s, float gv, float& a, float& gg) {   // a = gelu(s), gg = gv * gelu'(s)
+    float e2;
+    const float cdf = 0.5f * (1.0f + fast_erf(s * 0.70710678118654752440f, &e2));
+    a = s * cdf;
+    gg = gv * (cdf + s * (e2 * 0.39894228040143267794f));
+}
 
 template <int CPL> struct Cols;
 template <> struct Cols<1> {
@@ -64,7 +76,11 @@ template <> struct Cols<2> {
 // LDS (floats): tile [NT*K*D] | acc [(R + kSlotRows)][AS] | ghs [NT][AS] | ths [8][AS] | meta [2*kWavesTG] (uint32)
 // AS = the block's column count (gridDim.y == 1: D).  acc rows R.. are the first-run slots.
 // BF: g holds bf16 rows (KPGNN_STORE_BF16); they are widened on the way into the LDS tile, everything behind is fp32.
-template <int CPL, bool VEC4, bool BF = false>
+// FUSE (CPL 2, fp32, one column block): the tile is not copied from g but COMPUTED - the backward of the fused KP-GIN+
+// epilogue  g = theta[k] * gh[i] * gelu'(S[i,k])  (kpgnn_combine_bwd's arithmetic): wave w owns hop w, reads its 8 rows of S
+// (one 416-byte row per request, next tile's rows in flight), writes them to g AND to the LDS tile, and keeps the theta
+// gradient of its hop in two registers for the whole launch.  g is then never read back for the table gradients.
+template <int CPL, bool VEC4, bool BF = false, bool FUSE = false>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // (HIP: waves per SIMD) two blocks per CU: 128 VGPRs
 table_grad_kernel(const TgParams p, int AS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -80,11 +96,14 @@ table_grad_kernel(const TgParams p, int AS) {
     const int tile_floats = p.NT * K * D;
     float* tile = lds;
     float* acc = lds + ((tile_floats + 3) & ~3);
-    float* ghs = acc + (R + kSlotRows) * AS;
-    float* ths = ghs + 8 * AS;
-    uint32_t* meta = reinterpret_cast<uint32_t*>(ths + 8 * AS);
+    float* ghs = acc + (R + kSlotRows) * AS;          // FUSE: two buffers of 8 rows (this tile's / the next tile's gh rows)
+    float* ths = ghs + (FUSE ? 16 : 8) * AS;
+    float* ptl = ths + 8 * AS;                        // FUSE: the dictionary rows (theta gradient)
+    uint32_t* meta = reinterpret_cast<uint32_t*>(ptl + (FUSE ? p.f_U * AS : 0));
     for (int i = threadIdx.x; i < (R + kSlotRows) * AS; i += kThreadsTG) acc[i] = 0.f;
-    if (p.dict_src == 1)
+    if (FUSE)
+        for (int i = threadIdx.x; i < p.f_U * AS; i += kThreadsTG) ptl[i] = p.f_ptab[i];   // (AS == D)
+    if (p.dict_src == 1 || FUSE)
         for (int i = threadIdx.x; i < 8 * AS; i += kThreadsTG) {
             const int k = i / AS, q = i - k * AS;
             ths[i] = (k < K && cb + q < D) ? p.theta[k * D + cb + q] : 0.f;
@@ -113,7 +132,23 @@ table_grad_kernel(const TgParams p, int AS) {
             *reinterpret_cast<float4*>(dst) = v;
         }
     };
-    if (VEC4) {
+    // FUSE: the 8 rows (node n, hop w) of S of a tile, two columns per lane - they live in the same 16 registers as pref[]
+    auto load_s_rows = [&](int64_t t2, int k2, int sub, int step) {
+        float2* sp = reinterpret_cast<float2*>(pref);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = sub + j * step;
+            const int64_t node = t2 * p.NT + n;
+            sp[j] = make_float2(0.f, 0.f);
+            if (t2 < num_tiles && n < p.NT && node < p.N && k2 < K && col_ok)
+                sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + k2) * (int64_t)D + c);
+        }
+    };
+    if (FUSE) {
+        int kp = 1; while (kp < K) kp <<= 1;
+        const int wph0 = kWavesTG / kp;
+        load_s_rows(blockIdx.x, w / wph0, w % wph0, wph0);
+    } else if (VEC4) {
 #pragma unroll
         for (int q = 0; q < kPref; ++q) {
             const int64_t i = (int64_t)blockIdx.x * tile_floats + (q * kThreadsTG + threadIdx.x) * EPL;
@@ -125,7 +160,7 @@ table_grad_kernel(const TgParams p, int AS) {
     // Per-tile metadata travels ahead in registers: the entry-list window (tile_ptr) of tile i+2 and, from the window
     // that arrived an iteration ago, this wave's entries / dictionary entries / gh row of tile i+1, so that no dependent
     // global round trip (tile_ptr -> tile_pack) sits in front of a walk.
-    struct TileMeta { int beg, end; uint32_t nxt, dnx; CV gh; };
+    struct TileMeta { int beg, end; uint32_t nxt, dnx; CV gh; int fu; };
     auto load_range = [&](int64_t t2) -> int {       // lane 0: begin of the tile's window, lane 1: its end
         int v = 0;
         if (p.tptr && t2 < num_tiles && lane < 2) v = p.tptr[t2 + lane];
@@ -142,8 +177,17 @@ table_grad_kernel(const TgParams p, int AS) {
             m.dnx = p.dpack[t2 * 64 + w * 8 + lane];
         }
         m.gh.zero();                                  // wave w stages the gh row of the tile's node w
-        const int64_t node = t2 * p.NT + w;
-        if (p.dict_src == 1 && w < p.NT && t2 < num_tiles && node < p.N && col_ok) m.gh.load(p.gh + node * D + cb + c);
+        // (FUSE: of the tile AFTER t2 - the compute phase of a tile needs all 8 rows in LDS before its first barrier, so they
+        //  are stored one tile early into the other of two buffers)
+        const int64_t tg = FUSE ? t2 + gridDim.x : t2;
+        const int64_t node = tg * p.NT + w;
+        if ((p.dict_src == 1 || FUSE) && w < p.NT && tg < num_tiles && node < p.N && col_ok) m.gh.load(p.gh + node * D + cb + c);
+        m.fu = 0;                                     // FUSE: lane n < 8: dictionary id of (node n of tile t2, this wave's hop)
+        if (FUSE && p.f_uid && lane < p.NT && t2 < num_tiles && t2 * p.NT + lane < p.N) {
+            int kp = 1; while (kp < K) kp <<= 1;
+            const int k2 = w / (kWavesTG / kp);
+            if (k2 < K) m.fu = p.f_uid[(t2 * p.NT + lane) * p.f_uid_stride + k2];
+        }
     };
     TileMeta cm;
     int rng1;
@@ -151,6 +195,24 @@ table_grad_kernel(const TgParams p, int AS) {
         const int rng0 = load_range(blockIdx.x);
         load_meta(blockIdx.x, __builtin_amdgcn_readlane(rng0, 0), __builtin_amdgcn_readlane(rng0, 1), cm);
         rng1 = load_range((int64_t)blockIdx.x + gridDim.x);
+    }
+    // FUSE: wave w computes hop fk for the nodes n = fsub, fsub + wph, ... of a tile; with K <= 4 hops several waves share a
+    // hop (wph = 8 / pow2ceil(K)) so that the compute phase keeps all waves busy for the early layers too
+    int wph = 1;
+    if (FUSE) { int kp = 1; while (kp < K) kp <<= 1; wph = kWavesTG / kp; }
+    const int fk = w / wph, fsub = w - fk * wph;
+    const bool fwave = FUSE && fk < K;
+    int gbuf = 0;                                     // FUSE: ghs buffer that holds the CURRENT tile's gh rows
+    float gth_a = 0.f, gth_b = 0.f;                   // FUSE: theta gradient of hop w, this lane's two columns
+    float th_a = 0.f, th_b = 0.f;
+    if (FUSE) {
+        const int64_t node = (int64_t)blockIdx.x * p.NT + w;
+        CV g0;
+        g0.zero();
+        if (w < p.NT && blockIdx.x < num_tiles && node < p.N && col_ok) g0.load(p.gh + node * D + c);
+        if (w < p.NT && col_ok) g0.store(ghs + w * AS + cc);
+        if (fwave && col_ok) { th_a = p.theta[fk * D + c]; th_b = p.theta[fk * D + c + 1]; }
+        __syncthreads();
     }
     // what a finished walk leaves for the boundary pass: the last run of each list (registers) and the packed chunk
     // description  nonempty | whole << 1 | first_row << 2 | last_row << 14
@@ -233,7 +295,35 @@ table_grad_kernel(const TgParams p, int AS) {
             boundary(1, myD, lastD, metav);
         }
         have_prev = true;
-        if (VEC4) {
+        if (FUSE) {
+            // next tile's gh row of this wave -> the other buffer (its last readers were the previous tile's walk)
+            if (w < p.NT && col_ok) ghv.store(ghs + ((gbuf ^ 1) * 8 + w) * AS + cc);
+            const int fuv = cm.fu;
+            const float2* sp = reinterpret_cast<const float2*>(pref);
+            if (fwave) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = fsub + j * wph;
+                    const int64_t node = tl * p.NT + n;
+                    if (n >= p.NT || node >= p.N) break;                       // (wave-uniform)
+                    const float2 gh2 = *reinterpret_cast<const float2*>(ghs + (gbuf * 8 + n) * AS + cc);
+                    const float2 s2 = sp[j];
+                    float a0, a1, g0, g1;
+                    gelu_bwd2(s2.x, th_a * gh2.x, a0, g0);
+                    gelu_bwd2(s2.y, th_b * gh2.y, a1, g1);
+                    float2 pr = make_float2(0.f, 0.f);
+                    if (p.f_uid) pr = *reinterpret_cast<const float2*>(ptl + __builtin_amdgcn_readlane(fuv, n) * AS + cc);
+                    gth_a = fmaf(gh2.x, a0 + pr.x, gth_a);
+                    gth_b = fmaf(gh2.y, a1 + pr.y, gth_b);
+                    if (col_ok) {
+                        *reinterpret_cast<float2*>(p.f_g + (node * K + fk) * (int64_t)D + c) = make_float2(g0, g1);
+                        *reinterpret_cast<float2*>(tile + (n * K + fk) * D + c) = make_float2(g0, g1);
+                    }
+                }
+            }
+            load_s_rows(tl + gridDim.x, fk, fsub, wph);
+            gbuf ^= 1;
+        } else if (VEC4) {
             // the first kPref*2048 floats of the tile were prefetched into registers during the previous walk
 #pragma unroll
             for (int q = 0; q < kPref; ++q) {
@@ -253,7 +343,7 @@ table_grad_kernel(const TgParams p, int AS) {
             for (int i = threadIdx.x; i < nfl; i += kThreadsTG)
                 tile[i] = BF ? __uint_as_float((uint32_t)gbf[base + i] << 16) : p.g[base + i];
         }
-        if (p.dict_src == 1 && w < p.NT && col_ok) ghv.store(ghs + w * AS + cc);
+        if (!FUSE && p.dict_src == 1 && w < p.NT && col_ok) ghv.store(ghs + w * AS + cc);
         __syncthreads();
         // ---- walk this wave's chunk of the (table,code)-sorted pair list.  Every lane decodes ITS entry once (VALU, 64
         //      entries per instruction); per entry the wave then pays three v_readlane, one LDS read, a compare and the fma.
@@ -409,6 +499,8 @@ table_grad_kernel(const TgParams p, int AS) {
         const int r = i / AS, q = i - r * AS;
         if (cb + q < D) p.slab[((int64_t)blockIdx.x * R + r) * D + cb + q] = acc[i];
     }
+    if (FUSE && p.f_gth && fwave && col_ok)      // slab row = (block, sub-wave of the hop): gridDim.x * wph partial [K,D] tables
+        *reinterpret_cast<float2*>(p.f_gth + (((int64_t)blockIdx.x * wph + fsub) * K + fk) * D + c) = make_float2(gth_a, gth_b);
 }
 
 // Dictionary entries of every tile, sorted by dictionary row: pack[tile*64 + j] = uid << 8 | node_in_tile << 3 | hop.
@@ -488,7 +580,7 @@ namespace {
 
 struct Plan { int grid_x, grid_y, cpl, AS; size_t lds, ws_bytes; int R; };
 
-int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
+int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl, int extra_rows = 0) {
     if (NT * K > kMaxRows || K > 8 || NT > 8)
         return fail(KPGNN_ELIMIT, "table_grad: nodes_per_tile=%d x K=%d exceeds the %d-row (8x8) register tile", NT, K, kMaxRows);
     pl->R = n0 + nk + U;
@@ -497,7 +589,7 @@ int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     const int cols = kWave * pl->cpl;
     pl->grid_y = (D + cols - 1) / cols;
     pl->AS = pl->grid_y == 1 ? D : cols;
-    pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)pl->AS * (pl->R + kSlotRows + 16)) + 2 * kWavesTG * 4;
+    pl->lds = sizeof(float) * ((((size_t)NT * K * D + 3) & ~(size_t)3) + (size_t)pl->AS * (pl->R + kSlotRows + 16 + extra_rows)) + 2 * kWavesTG * 4;
     if (pl->lds > 160 * 1024)
         return fail(KPGNN_ELIMIT, "table_grad: %zu B of LDS needed (tile %dx%d rows + %d table rows)", pl->lds, NT, K, pl->R);
     const int64_t num_tiles = ((int64_t)N + NT - 1) / NT;
@@ -511,10 +603,10 @@ int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl) {
     return KPGNN_OK;
 }
 
-template <int CPL, bool VEC4, bool BF = false>
+template <int CPL, bool VEC4, bool BF = false, bool FUSE = false>
 int launch_walk(const TgParams& p, const Plan& pl, hipStream_t s) {
-    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4, BF>, pl.lds));
-    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4, BF>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4, BF, FUSE>, pl.lds));
+    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4, BF, FUSE>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
     KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return KPGNN_OK;
 }
@@ -531,6 +623,11 @@ extern "C" size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t
     const size_t mfma = table_grad_mfma_ws_bytes(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict);
     if (make_plan(N, K, D, nodes_per_tile, n_code0, K > 1 ? n_codek : 0, n_dict, &pl) != KPGNN_OK) return mfma;
     return pl.ws_bytes > mfma ? pl.ws_bytes : mfma;  // 0 means "neither kernel fits": the caller takes its atomic fallback
+}
+
+extern "C" size_t kpgnn_table_grad_fuse_workspace_bytes(int32_t K, int32_t D) {
+    // per block up to 8 / pow2ceil(K) partial [K,D] tables (several waves share a hop when K <= 4): K * that <= 8 rows
+    return K >= 1 && D >= 1 ? sizeof(float) * (size_t)device_facts().cu_count * 2 * 8 * D : 0;
 }
 
 extern "C" int kpgnn_dict_tile_pack(const int32_t* uid, int64_t uid_stride, int32_t N, int32_t K, int32_t nodes_per_tile,
@@ -551,7 +648,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->K <= 4096 && d->D >= 1 && d->nodes_per_tile >= 1 && d->nodes_per_tile <= 8,
                   "table_grad: bad N=%d K=%d D=%d nodes_per_tile=%d", d->N, d->K, d->D, d->nodes_per_tile);
     if (d->N == 0) return KPGNN_OK;
-    KPGNN_REQUIRE(d->g != nullptr, "table_grad: NULL g");
+    KPGNN_REQUIRE(d->g != nullptr || d->fuse_pre != nullptr, "table_grad: NULL g");
     const bool edges = d->tile_ptr != nullptr;
     KPGNN_REQUIRE(!edges || (d->gtable0 && d->n_code0 >= 1 && (d->K == 1 || (d->gtablek && d->n_codek >= 1))),
                   "table_grad: missing gtable0/gtablek");
@@ -563,6 +660,43 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     KPGNN_REQUIRE(edges || d->n_dict > 0, "table_grad: nothing to do");
     KPGNN_REQUIRE(!d->extra_slab || (d->extra_out && d->extra_nslab >= 1 && d->extra_elems >= 1), "table_grad: bad extra slab");
     hipStream_t s = (hipStream_t)stream;
+    if (d->fuse_pre) {
+        // Combine backward fused in: g = theta[k] * gh[i] * gelu'(S[i,k]) is computed per tile, written to fuse_g and walked
+        // from LDS; the theta gradient leaves through fuse_workspace.  Edge-code tables only (the dictionary gradient has its
+        // own kernel), fp32, one column block.
+        KPGNN_REQUIRE(edges && d->n_dict == 0 && d->storage == KPGNN_STORE_F32 && d->K <= 8 && d->nodes_per_tile == 8 &&
+                      d->D % 2 == 0 && d->D <= 2 * kWave && d->theta && d->gh && d->fuse_g,
+                      "table_grad(fused combine): needs the edge lists, no dictionary rows, fp32, K <= 8, tiles of 8 nodes, even D <= 128, theta, gh, fuse_g");
+        KPGNN_REQUIRE(!d->fuse_uid || (d->fuse_ptab && d->fuse_n_dict >= 1 && d->fuse_uid_stride >= d->K), "table_grad(fused combine): bad dictionary");
+        KPGNN_REQUIRE(!d->fuse_gtheta || (d->fuse_workspace && d->fuse_workspace_bytes >= kpgnn_table_grad_fuse_workspace_bytes(d->K, d->D)),
+                      "table_grad(fused combine): theta-gradient workspace too small");
+        KPGNN_REQUIRE(!d->fuse_galphas || (d->fuse_alphas && d->fuse_gtheta), "table_grad(fused combine): galphas needs alphas and gtheta");
+        TgParams p;
+        p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
+        p.n0 = d->n_code0; p.nk = d->K > 1 ? d->n_codek : 0; p.U = 0; p.dict_src = 0; p.KD = 0;
+        p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = nullptr;
+        p.uid = nullptr; p.uid_stride = 0; p.dpack = nullptr; p.theta = d->theta; p.gh = d->gh;
+        p.f_pre = d->fuse_pre; p.f_ptab = d->fuse_uid ? d->fuse_ptab : nullptr; p.f_uid = d->fuse_uid; p.f_uid_stride = d->fuse_uid_stride;
+        p.f_U = d->fuse_uid ? d->fuse_n_dict : 0; p.f_g = d->fuse_g; p.f_gth = d->fuse_gtheta ? (float*)d->fuse_workspace : nullptr;
+        Plan pl;
+        int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, 0, &pl, 8 + p.f_U);
+        if (rc != KPGNN_OK) return rc;
+        KPGNN_REQUIRE(pl.grid_y == 1 && pl.cpl == 2, "table_grad(fused combine): one column block of two columns per lane expected");
+        KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
+                      (size_t)d->workspace_bytes, pl.ws_bytes);
+        p.slab = (float*)d->workspace;
+        rc = launch_walk<2, false, false, true>(p, pl, s);
+        if (rc != KPGNN_OK) return rc;
+        rc = slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
+                         (int64_t)p.nk * p.D, nullptr, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
+        if (rc != KPGNN_OK || !d->fuse_gtheta) return rc;
+        int kp = 1;
+        while (kp < d->K) kp <<= 1;
+        const int nslab = pl.grid_x * (kWavesTG / kp);
+        if (d->fuse_galphas)
+            return gtheta_finish_launch(p.f_gth, nslab, d->fuse_alphas, d->theta, d->K, d->D, d->fuse_gtheta, d->fuse_galphas, s);
+        return slab_reduce(p.f_gth, nslab, (int64_t)d->K * d->D, d->fuse_gtheta, (int64_t)d->K * d->D, nullptr, 0, nullptr, s);
+    }
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
         // count-matrix product on the matrix cores: measured 56 vs 68 us (edge codes) and 70 vs 299 us (with unsorted
@@ -592,6 +726,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     // the sorted dictionary list addresses hops with the stride it was built for; it only applies when that is g's K
     // (a list built for all K hops serves every layer: entries of hops >= d->K are skipped)
     p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.KD = d->dict_pack_K;
+    p.f_pre = nullptr; p.f_ptab = nullptr; p.f_uid = nullptr; p.f_uid_stride = 0; p.f_U = 0; p.f_g = nullptr; p.f_gth = nullptr;
     Plan pl;
     int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl);
     if (rc != KPGNN_OK) return rc;

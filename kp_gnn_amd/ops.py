@@ -368,6 +368,66 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     return gt0, gtk, gd
 
 
+def _combine_table_grad_ok(csr, pre):
+    N, K, D = pre.shape
+    return (pre.dtype == torch.float32 and K <= 8 and D % 2 == 0 and D <= 128 and csr.nodes_per_tile == 8
+            and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0)
+
+
+def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None):
+    """kpgnn_table_grad with the combine backward fused in (KP-GIN+ epilogue, fp32): computes g = theta[k]*gh[i]*gelu'(S[i,k]),
+    the edge-code table gradients from it and (want_gtheta) the theta gradient / d/dalphas - `g` is written once and never read
+    back for the tables.  Returns (g, gtheta or (gtheta, galphas) or None, gtable0, gtablek), or None when the shape has no
+    fused kernel (the caller then runs combine_bwd_raw + table_grad_raw)."""
+    lib = _lib.load()
+    N, K, D = pre.shape
+    dev = pre.device
+    if not _combine_table_grad_ok(csr, pre):
+        return None
+    nk = n_codek if K > 1 else 0
+    ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n_code0, 1), nk, 0)
+    if ws_bytes == 0:
+        return None
+    d = _lib.TableGradDesc()
+    d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, nk
+    tptr, tpack = csr.tile_list(K)
+    d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
+    d.g_sn, d.g_sk = K * D, D
+    gh = gh.contiguous()
+    theta = theta.contiguous()
+    d.theta, d.gh = theta.data_ptr(), gh.data_ptr()
+    gt0 = torch.empty((n_code0, D), dtype=torch.float32, device=dev)
+    gtk = torch.empty((nk, D), dtype=torch.float32, device=dev) if nk > 0 else None
+    d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
+    ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    d.fuse_pre, d.fuse_g = pre.data_ptr(), g.data_ptr()
+    if uid is not None and ptab is not None:
+        d.fuse_ptab, d.fuse_uid, d.fuse_uid_stride, d.fuse_n_dict = ptab.data_ptr(), uid.data_ptr(), uid.stride(0), ptab.shape[0]
+    gth = gal = fws = None
+    if want_gtheta:
+        gth = torch.empty((K, D), dtype=torch.float32, device=dev)
+        nb = int(lib.kpgnn_table_grad_fuse_workspace_bytes(K, D))
+        fws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        d.fuse_gtheta, d.fuse_workspace, d.fuse_workspace_bytes = gth.data_ptr(), fws.data_ptr(), nb
+        if alphas is not None:
+            gal = torch.empty_like(alphas)
+            d.fuse_alphas, d.fuse_galphas = alphas.data_ptr(), gal.data_ptr()
+    if extra is not None:
+        d.extra_out, d.extra_slab, d.extra_nslab, d.extra_elems = extra[0].data_ptr(), extra[1].data_ptr(), extra[2], extra[0].numel()
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_table_grad(ctypes.byref(d), _stream(pre)), "kpgnn_table_grad")
+        if _timer is not None:
+            e1.record()     # S read, g written, gh read, pair list, tables
+            _timer.records.append(("combine_table_grad", 8 * N * K * D + 4 * N * D + 4 * csr.active_pairs(K)
+                                   + 4 * D * (n_code0 + nk), e0, e1))
+    return g, ((gth, gal) if gal is not None else gth), gt0, gtk
+
+
 def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want_gv, alphas=None):
     """Launch kpgnn_combine_bwd.  gout is gh [N,D] when theta is given, else dL/dout [N,K,D].
     Returns (g, gv or None, gtheta or None); with `alphas` (geometric combine) the third is (gtheta, galphas)."""
@@ -490,7 +550,35 @@ class KHopAggregate(torch.autograd.Function):
         gtheta = gperiph = gdict = None
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        if fused or need_act:
+        gt0 = gtk = None
+        tables_in_gather = False
+        done = False
+        # --- KP-GIN+ with the fused geometric combine, dictionary P and edge-code tables: ONE kernel computes dL/dS from S and
+        #     gh, writes it for the gather below and takes the table gradients from the LDS copy of each tile; the dictionary
+        #     gradient comes from gh alone (dict_grad), its partial sums added up by the same finishing launch
+        if (fused and mode == MODE_GINPLUS and want_tables and periph is None and not want_gperiph
+                and _combine_table_grad_ok(csr, pre)):
+            extra = dg = None
+            if want_gdict and pre.shape[0] >= 4096:
+                dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)
+                extra = dg
+            r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
+                                       want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra)
+            if r is not None:
+                g, gtheta, gt0, gtk = r
+                if isinstance(gtheta, tuple):
+                    gtheta = gtheta[1]
+                    galphas_done = True
+                if dg is not None:
+                    gdict = dg[0]
+                elif want_gdict:          # small batches: the dictionary rows ride along a walk over g (as before)
+                    gdict = table_grad_raw(csr, g, 0, 0, edges=False, uid=uid, n_dict=ctx.n_dict, theta=theta, gh=gout)[2]
+                done = True
+            elif dg is not None:
+                raise _lib.KpgnnError("table_grad refused a shape after dict_grad deferred its reduction to it")
+        if done:
+            pass
+        elif fused or need_act:
             g, gv, gtheta = combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid,
                                             want_gtheta=fused and ctx.needs_input_grad[5],
                                             want_gv=fused and want_gperiph, alphas=ctx.alphas if fused else None)
@@ -502,9 +590,7 @@ class KHopAggregate(torch.autograd.Function):
             g = gout
             gperiph = gout if want_gperiph else None
         # --- table gradients (edge codes + peripheral dictionary), column-private kernel
-        gt0 = gtk = None
-        tables_in_gather = False
-        if want_tables or want_gdict:
+        if not done and (want_tables or want_gdict):
             edges_here = want_tables and mode != MODE_GCN   # GCN weights its table grads per edge: fused atomics
             dict_here = want_gdict and (fused or not need_act)  # g == dL/dP only without an activation
             res = None
