@@ -428,7 +428,9 @@ table_grad_kernel(const TgParams p, int AS) {
             const bool dok = dmine != 0xFFFFFFFFu && (int)(dmine & 7) < K;
             const int dn = (dmine >> 3) & 7, dk = dmine & 7;
             const int drow = dok ? p.n0 + p.nk + (int)(dmine >> 8) : -1;
-            const int doa = p.dict_src == 1 ? dn * AS : (dn * K + dk) * D + cb;   // gh row / g row of the tile
+            // gh row / g row of the tile (FUSE: the tile's gh rows sit in the buffer the compute phase just read - gbuf was
+            // toggled behind it)
+            const int doa = p.dict_src == 1 ? ((FUSE ? (gbuf ^ 1) * 8 : 0) + dn) * AS : (dn * K + dk) * D + cb;
             const int dob = dk * AS;                                              // theta row
             int cur = -1, first_row = 0;
             bool first = true;
@@ -664,22 +666,24 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // Combine backward fused in: g = theta[k] * gh[i] * gelu'(S[i,k]) is computed per tile, written to fuse_g and walked
         // from LDS; the theta gradient leaves through fuse_workspace.  Edge-code tables only (the dictionary gradient has its
         // own kernel), fp32, one column block.
-        KPGNN_REQUIRE(edges && d->n_dict == 0 && d->storage == KPGNN_STORE_F32 && d->K <= 8 && d->nodes_per_tile == 8 &&
+        KPGNN_REQUIRE(edges && d->storage == KPGNN_STORE_F32 && d->K <= 8 && d->nodes_per_tile == 8 &&
                       d->D % 2 == 0 && d->D <= 2 * kWave && d->theta && d->gh && d->fuse_g,
-                      "table_grad(fused combine): needs the edge lists, no dictionary rows, fp32, K <= 8, tiles of 8 nodes, even D <= 128, theta, gh, fuse_g");
+                      "table_grad(fused combine): needs the edge lists, fp32, K <= 8, tiles of 8 nodes, even D <= 128, theta, gh, fuse_g");
+        KPGNN_REQUIRE(d->n_dict == 0 || (d->dict_src == 1 && d->dict_pack && d->gdict && d->dict_pack_K >= d->K && d->dict_pack_K <= 8),
+                      "table_grad(fused combine): dictionary rows need dict_src 1, gdict and the uid-sorted list of kpgnn_dict_tile_pack");
         KPGNN_REQUIRE(!d->fuse_uid || (d->fuse_ptab && d->fuse_n_dict >= 1 && d->fuse_uid_stride >= d->K), "table_grad(fused combine): bad dictionary");
         KPGNN_REQUIRE(!d->fuse_gtheta || (d->fuse_workspace && d->fuse_workspace_bytes >= kpgnn_table_grad_fuse_workspace_bytes(d->K, d->D)),
                       "table_grad(fused combine): theta-gradient workspace too small");
         KPGNN_REQUIRE(!d->fuse_galphas || (d->fuse_alphas && d->fuse_gtheta), "table_grad(fused combine): galphas needs alphas and gtheta");
         TgParams p;
         p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
-        p.n0 = d->n_code0; p.nk = d->K > 1 ? d->n_codek : 0; p.U = 0; p.dict_src = 0; p.KD = 0;
+        p.n0 = d->n_code0; p.nk = d->K > 1 ? d->n_codek : 0; p.U = d->n_dict; p.dict_src = d->n_dict > 0 ? 1 : 0; p.KD = d->dict_pack_K;
         p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = nullptr;
-        p.uid = nullptr; p.uid_stride = 0; p.dpack = nullptr; p.theta = d->theta; p.gh = d->gh;
+        p.uid = d->uid; p.uid_stride = d->uid_stride; p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.theta = d->theta; p.gh = d->gh;
         p.f_pre = d->fuse_pre; p.f_ptab = d->fuse_uid ? d->fuse_ptab : nullptr; p.f_uid = d->fuse_uid; p.f_uid_stride = d->fuse_uid_stride;
         p.f_U = d->fuse_uid ? d->fuse_n_dict : 0; p.f_g = d->fuse_g; p.f_gth = d->fuse_gtheta ? (float*)d->fuse_workspace : nullptr;
         Plan pl;
-        int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, 0, &pl, 8 + p.f_U);
+        int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl, 8 + p.f_U);
         if (rc != KPGNN_OK) return rc;
         KPGNN_REQUIRE(pl.grid_y == 1 && pl.cpl == 2, "table_grad(fused combine): one column block of two columns per lane expected");
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
@@ -688,7 +692,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         rc = launch_walk<2, false, false, true>(p, pl, s);
         if (rc != KPGNN_OK) return rc;
         rc = slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
-                         (int64_t)p.nk * p.D, nullptr, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
+                         (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
         if (rc != KPGNN_OK || !d->fuse_gtheta) return rc;
         int kp = 1;
         while (kp < d->K) kp <<= 1;

@@ -374,22 +374,34 @@ def _combine_table_grad_ok(csr, pre):
             and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0)
 
 
-def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None):
+def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None,
+                           dict_rows=0):
     """kpgnn_table_grad with the combine backward fused in (KP-GIN+ epilogue, fp32): computes g = theta[k]*gh[i]*gelu'(S[i,k]),
     the edge-code table gradients from it and (want_gtheta) the theta gradient / d/dalphas - `g` is written once and never read
     back for the tables.  Returns (g, gtheta or (gtheta, galphas) or None, gtable0, gtablek), or None when the shape has no
-    fused kernel (the caller then runs combine_bwd_raw + table_grad_raw)."""
+    fused kernel (the caller then runs combine_bwd_raw + table_grad_raw).
+    dict_rows > 0: the dictionary gradient (theta[k]*gh[i] per (node, hop) id) rides along the walk and is returned as a
+    fifth value (small batches, where a separate dict_grad launch costs more than it saves)."""
     lib = _lib.load()
     N, K, D = pre.shape
     dev = pre.device
     if not _combine_table_grad_ok(csr, pre):
         return None
     nk = n_codek if K > 1 else 0
-    ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n_code0, 1), nk, 0)
+    gd = None
+    if dict_rows > 0:
+        pack, kf = dict_tile_pack(csr, uid)
+        if pack is None:
+            return None
+    ws_bytes = lib.kpgnn_table_grad_workspace_bytes(N, K, D, csr.nodes_per_tile, max(n_code0, 1), nk, dict_rows)
     if ws_bytes == 0:
         return None
     d = _lib.TableGradDesc()
     d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, nk
+    if dict_rows > 0:
+        gd = torch.empty((dict_rows, D), dtype=torch.float32, device=dev)
+        d.n_dict, d.dict_src, d.uid, d.uid_stride, d.gdict = dict_rows, 1, uid.data_ptr(), uid.stride(0), gd.data_ptr()
+        d.dict_pack, d.dict_pack_K = pack.data_ptr(), kf
     tptr, tpack = csr.tile_list(K)
     d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
     d.g_sn, d.g_sk = K * D, D
@@ -425,6 +437,8 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
             e1.record()     # S read, g written, gh read, pair list, tables
             _timer.records.append(("combine_table_grad", 8 * N * K * D + 4 * N * D + 4 * csr.active_pairs(K)
                                    + 4 * D * (n_code0 + nk), e0, e1))
+    if dict_rows > 0:
+        return g, ((gth, gal) if gal is not None else gth), gt0, gtk, gd
     return g, ((gth, gal) if gal is not None else gth), gt0, gtk
 
 
@@ -562,16 +576,23 @@ class KHopAggregate(torch.autograd.Function):
             if want_gdict and pre.shape[0] >= 4096:
                 dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)
                 extra = dg
+            in_walk = ctx.n_dict if (want_gdict and dg is None) else 0   # small batches: the dictionary rows ride along
             r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
-                                       want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra)
+                                       want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra, dict_rows=in_walk)
+            if r is None and in_walk:
+                r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
+                                           want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas)
+                in_walk = 0
             if r is not None:
-                g, gtheta, gt0, gtk = r
+                g, gtheta, gt0, gtk = r[:4]
                 if isinstance(gtheta, tuple):
                     gtheta = gtheta[1]
                     galphas_done = True
                 if dg is not None:
                     gdict = dg[0]
-                elif want_gdict:          # small batches: the dictionary rows ride along a walk over g (as before)
+                elif in_walk:
+                    gdict = r[4]
+                elif want_gdict:
                     gdict = table_grad_raw(csr, g, 0, 0, edges=False, uid=uid, n_dict=ctx.n_dict, theta=theta, gh=gout)[2]
                 done = True
             elif dg is not None:
