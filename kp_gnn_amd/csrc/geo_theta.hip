@@ -48,56 +48,9 @@ __global__ void geo_theta_bwd_kernel(const float* __restrict__ alpha, const floa
 // owns CB columns, thread (slice, o) adds every 16th slab row of output o = (k, column), the slices meet in LDS, then one
 // thread per column runs the K-term backward.  (Replaces slab_reduce + geo_theta_bwd: one launch less per layer.)
 __global__ void __launch_bounds__(1024)
-gtheta_finish_kernel(const float* __restrict__ slab, int nslab, const float* __restrict__ alpha,
-                     const float* __restrict__ theta, int K, int D, int CB, float* __restrict__ gtheta, float* __restrict__ galpha) {
-    __shared__ float part[16][65];
-    __shared__ float tot[64];
-    const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int k = o / CB, cq = o - k * CB;
-    const int d = blockIdx.x * CB + cq;
-    const bool ok = k < K && d < D;
-    const int64_t KD = (int64_t)K * D, e = (int64_t)k * D + d;
-    // theta / alpha of this block's columns are requested before the slab loop (their latency hides behind it)
-    __shared__ float ths[64];
-    float th_mine = 0.f, al_mine = 0.f;
-    if (slice == 0 && ok) th_mine = theta[e];
-    if (threadIdx.x < CB && blockIdx.x * CB + threadIdx.x < D) al_mine = alpha[blockIdx.x * CB + threadIdx.x];
-    float s = 0.f;
-    if (ok) {
-        int b = slice;
-        for (; b + 48 < nslab; b += 64) {
-            const float v0 = slab[(int64_t)b * KD + e], v1 = slab[(int64_t)(b + 16) * KD + e];
-            const float v2 = slab[(int64_t)(b + 32) * KD + e], v3 = slab[(int64_t)(b + 48) * KD + e];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; b < nslab; b += 16) s += slab[(int64_t)b * KD + e];
-    }
-    part[slice][o] = s;
-    __syncthreads();
-    if (slice == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += part[q][o];
-        tot[o] = t;
-        ths[o] = th_mine;
-        if (ok) gtheta[e] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < CB && blockIdx.x * CB + threadIdx.x < D) {
-        const int c = threadIdx.x, dd = blockIdx.x * CB + c;
-        const float a = 1.0f / (1.0f + __expf(-al_mine));
-        const float q = 1.0f - a;
-        float dot = 0.f;
-        for (int kk = 0; kk < K; ++kk) dot = fmaf(ths[kk * CB + c], tot[kk * CB + c], dot);
-        float acc = 0.f, pw = 1.0f, pwm1 = 0.f;
-        for (int kk = 0; kk < K; ++kk) {
-            const float dt = ths[kk * CB + c] * (tot[kk * CB + c] - dot);
-            acc = fmaf(dt, pw - (float)kk * a * pwm1, acc);
-            pwm1 = pw;
-            pw *= q;
-        }
-        galpha[dd] = a * q * acc;
-    }
+gtheta_finish_kernel(const ThetaFinish f) {
+    __shared__ float sm[1168];
+    theta_finish_block(f, blockIdx.x, sm);     // (kpgnn_common.h: shared with the table-gradient finishing launch)
 }
 
 }  // namespace
@@ -108,8 +61,9 @@ int gtheta_finish_launch(const float* slab, int nslab, const float* alpha, const
                          float* galpha, hipStream_t s) {
     if (K > 64) return fail(KPGNN_ELIMIT, "gtheta_finish: K=%d > 64", K);
     const int CB = 64 / K;                     // columns per block: CB * K <= 64 outputs
-    hipLaunchKernelGGL(gtheta_finish_kernel, dim3((D + CB - 1) / CB), dim3(1024), 0, s, slab, nslab, alpha, theta, K, D, CB,
-                       gtheta, galpha);
+    ThetaFinish f;
+    f.slab = slab; f.nslab = nslab; f.alpha = alpha; f.theta = theta; f.K = K; f.D = D; f.gtheta = gtheta; f.galpha = galpha;
+    hipLaunchKernelGGL(gtheta_finish_kernel, dim3((D + CB - 1) / CB), dim3(1024), 0, s, f);
     KPGNN_LAUNCH_CHECK("gtheta_finish_kernel");
     return KPGNN_OK;
 }

@@ -55,10 +55,71 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).
-// Optionally the same launch reduces a second, independent slab [nslab_b][elems_b] into out_b.
+// Optionally the same launch reduces a second, independent slab [nslab_b][elems_b] into out_b, and (tf) finishes a
+// theta-gradient slab: gtheta[k,d] = sum_b slab[b][k,d] in block order and galpha = d(theta)/d(alpha)^T gtheta (galpha may
+// be NULL: gtheta only).  One launch for everything a table-gradient call leaves behind.
+struct ThetaFinish {
+    const float* slab; int nslab;
+    const float* alpha; const float* theta; int K, D;
+    float* gtheta; float* galpha;
+};
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr, const float* slab_b = nullptr,
-                int nslab_b = 0, int64_t elems_b = 0, float* out_b = nullptr);
+                int nslab_b = 0, int64_t elems_b = 0, float* out_b = nullptr, const ThetaFinish* tf = nullptr);
+
+// A 1024-thread block's share of the theta finishing (block `blk` owns CB = 64 / K columns); sm: >= 1168 floats of LDS.
+__device__ __forceinline__ void theta_finish_block(const ThetaFinish& f, int blk, float* sm) {
+    float (*part)[65] = reinterpret_cast<float (*)[65]>(sm);      // [16][65]
+    float* tot = sm + 16 * 65;
+    float* ths = tot + 64;
+    const int K = f.K, D = f.D, CB = 64 / K;
+    const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int k = o / CB, cq = o - k * CB;
+    const int d = blk * CB + cq;
+    const bool ok = k < K && cq < CB && d < D;
+    const int64_t KD = (int64_t)K * D, e = (int64_t)k * D + d;
+    // theta / alpha of this block's columns are requested before the slab loop (their latency hides behind it)
+    float th_mine = 0.f, al_mine = 0.f;
+    if (slice == 0 && ok) th_mine = f.theta[e];
+    const bool colthread = threadIdx.x < CB && blk * CB + threadIdx.x < D;
+    if (colthread && f.galpha) al_mine = f.alpha[blk * CB + threadIdx.x];
+    float s = 0.f;
+    if (ok) {
+        int b = slice;
+        for (; b + 48 < f.nslab; b += 64) {
+            const float v0 = f.slab[(int64_t)b * KD + e], v1 = f.slab[(int64_t)(b + 16) * KD + e];
+            const float v2 = f.slab[(int64_t)(b + 32) * KD + e], v3 = f.slab[(int64_t)(b + 48) * KD + e];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < f.nslab; b += 16) s += f.slab[(int64_t)b * KD + e];
+    }
+    part[slice][o] = s;
+    __syncthreads();
+    if (slice == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][o];
+        tot[o] = t;
+        ths[o] = th_mine;
+        if (ok) f.gtheta[e] = t;
+    }
+    __syncthreads();
+    if (colthread && f.galpha) {
+        const int c = threadIdx.x, dd = blk * CB + c;
+        const float a = 1.0f / (1.0f + __expf(-al_mine));
+        const float q = 1.0f - a;
+        float dot = 0.f;
+        for (int kk = 0; kk < K; ++kk) dot = fmaf(ths[kk * CB + c], tot[kk * CB + c], dot);
+        float acc = 0.f, pw = 1.0f, pwm1 = 0.f;
+        for (int kk = 0; kk < K; ++kk) {
+            const float dt = ths[kk * CB + c] * (tot[kk * CB + c] - dot);
+            acc = fmaf(dt, pw - (float)kk * a * pwm1, acc);
+            pwm1 = pw;
+            pw *= q;
+        }
+        f.galpha[dd] = a * q * acc;
+    }
+}
 
 // theta[k,d] = softmax_k(a (1-a)^k), a = sigmoid(alpha[d])  (geo_theta.hip)
 int geo_theta_fwd_launch(const float* alpha, int K, int D, float* theta, hipStream_t s);

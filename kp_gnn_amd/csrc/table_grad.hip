@@ -529,8 +529,13 @@ __global__ void __launch_bounds__(1024)
 slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, float* __restrict__ out0, int64_t n_out0,
                    float* __restrict__ out1, int64_t n_out1, float* __restrict__ out2, int64_t n_out2,
                    float* __restrict__ out3, int nblocks_a, const float* __restrict__ slab_b, int nslab_b, int64_t elems_b,
-                   float* __restrict__ out_b) {
-    __shared__ float part[64][17];
+                   float* __restrict__ out_b, int nblocks_ab, const ThetaFinish tf) {
+    __shared__ float sm[1168];
+    if ((int)blockIdx.x >= nblocks_ab) {   // the last blocks finish a theta-gradient slab (kpgnn_common.h)
+        theta_finish_block(tf, (int)blockIdx.x - nblocks_ab, sm);
+        return;
+    }
+    float (*part)[17] = reinterpret_cast<float (*)[17]>(sm);      // [64][17]
     const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
     int64_t blk = blockIdx.x;
     if (blk >= nblocks_a) {           // the blocks behind the first slab's reduce a second, independent slab into out_b
@@ -566,14 +571,23 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
 
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2, float* out3, const float* slab_b, int nslab_b, int64_t elems_b,
-                float* out_b) {
+                float* out_b, const ThetaFinish* tf) {
     if (!slab_b || elems_b <= 0) { slab_b = nullptr; elems_b = 0; }
-    if (elems <= 0 && elems_b <= 0) return KPGNN_OK;
     if (elems < 0) elems = 0;
+    ThetaFinish f;
+    f.slab = nullptr; f.nslab = 0; f.alpha = f.theta = nullptr; f.K = 1; f.D = 0; f.gtheta = f.galpha = nullptr;
+    int nbt = 0;
+    if (tf && tf->slab && tf->D > 0) {
+        if (tf->K > 64) return fail(KPGNN_ELIMIT, "slab_reduce: theta finishing needs K <= 64 (K = %d)", tf->K);
+        f = *tf;
+        const int CB = 64 / f.K;
+        nbt = (f.D + CB - 1) / CB;
+    }
+    if (elems <= 0 && elems_b <= 0 && nbt == 0) return KPGNN_OK;
     if (!out3) n2 = elems;   // three outputs: the rest goes to out2
     const int nba = (int)((elems + 15) / 16), nbb = (int)((elems_b + 15) / 16);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nba + nbb)), dim3(1024), 0, s, slab, nslab, elems,
-                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nba + nbb + nbt)), dim3(1024), 0, s, slab, nslab, elems,
+                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b, nba + nbb, f);
     KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
     return KPGNN_OK;
 }
@@ -691,15 +705,18 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         p.slab = (float*)d->workspace;
         rc = launch_walk<2, false, false, true>(p, pl, s);
         if (rc != KPGNN_OK) return rc;
-        rc = slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
-                         (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
-        if (rc != KPGNN_OK || !d->fuse_gtheta) return rc;
-        int kp = 1;
-        while (kp < d->K) kp <<= 1;
-        const int nslab = pl.grid_x * (kWavesTG / kp);
-        if (d->fuse_galphas)
-            return gtheta_finish_launch(p.f_gth, nslab, d->fuse_alphas, d->theta, d->K, d->D, d->fuse_gtheta, d->fuse_galphas, s);
-        return slab_reduce(p.f_gth, nslab, (int64_t)d->K * d->D, d->fuse_gtheta, (int64_t)d->K * d->D, nullptr, 0, nullptr, s);
+        ThetaFinish tf;
+        tf.slab = nullptr; tf.nslab = 0; tf.alpha = d->fuse_alphas; tf.theta = d->theta; tf.K = d->K; tf.D = d->D;
+        tf.gtheta = d->fuse_gtheta; tf.galpha = d->fuse_galphas;
+        if (d->fuse_gtheta) {
+            int kp = 1;
+            while (kp < d->K) kp <<= 1;
+            tf.slab = p.f_gth; tf.nslab = pl.grid_x * (kWavesTG / kp);
+        }
+        // ONE finishing launch: table slabs, the dictionary-gradient slab a kpgnn_dict_grad left behind, the theta gradient
+        return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
+                           (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out,
+                           d->fuse_gtheta ? &tf : nullptr);
     }
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
