@@ -992,6 +992,50 @@ def test_dict_grad_matches_index_add_bitwise(N, k_act, D, U):
     assert ops.dict_grad_raw(uid, 4000, theta.to(dev), gh.to(dev)) is None      # does not fit LDS: the caller falls back
 
 
+@pytest.mark.parametrize("N,k_act,D,in_walk", [(1237, 8, 104, False), (1237, 8, 104, True), (3001, 3, 104, True), (515, 1, 64, False),
+                                                (800, 5, 96, True), (64, 2, 24, True)])
+def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk):
+    """kpgnn_table_grad with the combine backward fused in (KP-GIN+ path) against kpgnn_combine_bwd + kpgnn_table_grad run one
+    after the other on the same inputs: dL/dS, the theta gradient and d/dalphas, both edge-code tables and (in_walk) the
+    dictionary rows; hop-prefix views, several waves per hop (k <= 4), partial last tile; bitwise repeatable."""
+    from kp_gnn_amd import ops, _lib
+    from kp_gnn_amd.khop_csr import KHopCSR
+    import ctypes
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(N + 7 * k_act + D)
+    K, U = 8, 13
+    ei = torch.randint(0, N, (2, 9 * N), generator=g0)
+    code = (torch.rand(9 * N, K, generator=g0) ** 3 * 5).long() + 1
+    ea = code * (torch.rand(9 * N, K, generator=g0) < 0.4)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    pre = torch.randn(N, k_act, D, generator=g0).to(dev)
+    gh = torch.randn(N, D, generator=g0).to(dev)
+    alphas = torch.randn(D, generator=g0).to(dev)
+    ptab = torch.randn(U, D, generator=g0).to(dev)
+    uid = torch.randint(0, U, (N, K), generator=g0, dtype=torch.int32).to(dev)[:, :k_act]
+    theta = torch.empty(k_act, D, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.kpgnn_geo_theta_fwd(alphas.data_ptr(), k_act, D, theta.data_ptr(), torch.cuda.current_stream().cuda_stream), "theta")
+    g_ref, _, gth_ref = ops.combine_bwd_raw(ops.MODE_GINPLUS, pre, gh, theta, None, ptab, uid, want_gtheta=True, want_gv=False,
+                                            alphas=alphas)
+    t_ref = ops.table_grad_raw(csr, g_ref, 6, 6, edges=True, uid=uid, n_dict=U, theta=theta, gh=gh)
+    r = ops.combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, 6, 6, want_gtheta=True, alphas=alphas,
+                                   dict_rows=U if in_walk else 0)
+    r2 = ops.combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, 6, 6, want_gtheta=True, alphas=alphas,
+                                    dict_rows=U if in_walk else 0)
+    assert r is not None
+    for a, b in zip(r[:1] + (r[1][0], r[1][1]) + r[2:], r2[:1] + (r2[1][0], r2[1][1]) + r2[2:]):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), "fused kernel is not bitwise repeatable"
+    _close(r[0], g_ref.cpu(), "g", rtol=1e-5, atol=1e-6)
+    _close(r[1][0], gth_ref[0].cpu(), "gtheta", rtol=2e-4, atol=2e-5)
+    _close(r[1][1], gth_ref[1].cpu(), "galphas", rtol=2e-4, atol=2e-5)
+    _close(r[2], t_ref[0].cpu(), "gtable0", rtol=2e-4, atol=2e-5)
+    if k_act > 1:
+        _close(r[3], t_ref[1].cpu(), "gtablek", rtol=2e-4, atol=2e-5)
+    if in_walk:
+        _close(r[4], t_ref[2].cpu(), "gdict", rtol=2e-4, atol=2e-5)
+
+
 # ----------------------------------------------------------------------------- hipGraph capture: replay == eager
 def _small_body(model_name, combine, K, L, H):
     import argparse
