@@ -186,7 +186,9 @@ typedef struct kpgnn_agg_bwd_desc {
     float* gx_slot[16];
     /* Bit k set: ADD the gradient of hop slot k to what gx_slot[k] already holds (a state that several layers read as
      * a slot collects its gradient in one buffer instead of one tensor per reader plus an add each).  Two hop slots of
-     * one call must not share a buffer when either accumulates (KPGNN_EINVAL). */
+     * one call must not share a buffer when either accumulates (KPGNN_EINVAL).  With gx (one [N,K,D] tensor) bit k adds hop
+     * k's gradient to what gx[:, k, :] already holds: a state that the bodies' jumping-knowledge projection and the next
+     * norm's residual branch also read collects its whole gradient in one buffer (K <= 32). */
     uint32_t accumulate_mask;
     int32_t storage;            /* KPGNN_STORE_*: with BF16, g (storage) holds bf16 rows; g_sn / g_sk count elements */
 } kpgnn_agg_bwd_desc;

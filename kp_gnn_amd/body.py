@@ -383,6 +383,11 @@ class GNN(_KHopBody):
                 h_list[l] = h_list[l] + vn[batch]
             # norm (+ residual) in one pass whenever no dropout mask sits between them (as in GNNPlus below)
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
+            # (this layer is the LAST of the state's readers to run backward - the norm's residual branch and the
+            #  jumping-knowledge projection come later in the forward - so a layer that supports it may collect the state's
+            #  whole gradient in one buffer: ops.khop_aggregate(x_state=...))
+            if h_list[l].is_cuda:
+                h_list[l]._kp_last_reader = self.gnns[l]
             h = self.norms[l](self.gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph),
                               residual=h_list[l] if fuse_res else None)
             if l != self.num_layer - 1:

@@ -373,7 +373,9 @@ struct BwdParams {
 // TAB: 0 = no table grads, 1 = accumulate table grads in LDS then flush with global fp32 atomics,
 //      2 = straight global atomics (tables too large for LDS)
 // BF (the chunked gather, !GCN && TAB == 0, not GIN): g rows are bf16; the sums and gx stay fp32.
-template <int VEC, int G, bool GCN, int TAB, bool BF = false>
+// GXACC (chunked gather with ONE [N,K,D] output): bit k of acc_mask adds to what gx[:, k, :] already holds.  A separate
+// instantiation: the select between the two output forms inside the hop loop cost the slot path 10 us per launch.
+template <int VEC, int G, bool GCN, int TAB, bool BF = false, bool GXACC = false>
 __global__ void __launch_bounds__(kBlock, 6)
 agg_bwd_kernel(const BwdParams p) {
     const int MODE = p.mode;
@@ -444,7 +446,8 @@ agg_bwd_kernel(const BwdParams p) {
         auto epi_prefetch = [&](int kk) {
             if (!CHUNKED || !col_ok) return;
             if (MODE == KPGNN_MODE_GIN) nself = V<VEC>::load(p.g + (int64_t)kk * p.g_sk + c0 + j * p.g_sn);
-            if (!p.gx && ((p.acc_mask >> kk) & 1u)) nold = V<VEC>::load(p.gxs[kk] + j * p.gx_sn + c0);
+            if (GXACC) { if ((p.acc_mask >> kk) & 1u) nold = V<VEC>::load(p.gx + (int64_t)kk * p.gx_sk + j * p.gx_sn + c0); }
+            else if (!p.gx && ((p.acc_mask >> kk) & 1u)) nold = V<VEC>::load(p.gxs[kk] + j * p.gx_sn + c0);
         };
         int end_next = lane_meta ? __shfl(myrp, sg_lane0 + 1) : rp[1];
         if (CHUNKED) { prefetch(0, beg, end_next); epi_prefetch(0); }
@@ -466,7 +469,7 @@ agg_bwd_kernel(const BwdParams p) {
                 for (int u = 0; u < PF; ++u)
                     if (u < cn) acc.add(pr[u]);
                 if (MODE == KPGNN_MODE_GIN) acc.fma(eps1, nself);      // (this hop's epilogue operands arrived with its rows)
-                if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(nold);
+                if (GXACC ? ((p.acc_mask >> k) & 1u) != 0 : (!p.gx && ((p.acc_mask >> k) & 1u))) acc.add(nold);
                 if (pend_dst) { pend.store_stream(pend_dst); pend_dst = nullptr; }   // previous hop's result
                 if (k + 1 < p.K) { prefetch(k + 1, end, end_next); epi_prefetch(k + 1); }
                 int pos = beg + cn;
@@ -557,7 +560,7 @@ agg_bwd_kernel(const BwdParams p) {
                 pend = acc;
                 pend_dst = dst;
             } else {
-                if (!p.gx && ((p.acc_mask >> k) & 1u)) acc.add(V<VEC>::load(dst));
+                if ((GXACC || !p.gx) && ((p.acc_mask >> k) & 1u)) acc.add(V<VEC>::load(dst));
                 acc.store(dst);
             }
         }
@@ -637,14 +640,14 @@ int launch_fwd_mode(const FwdParams& p, int tab, size_t lds, hipStream_t s) {
     }
 }
 
-template <int VEC, int G, bool GCN, int TAB, bool BF = false>
+template <int VEC, int G, bool GCN, int TAB, bool BF = false, bool GXACC = false>
 int launch_bwd(const BwdParams& p, size_t lds, hipStream_t s) {
     const int64_t tiles = ((int64_t)p.N + (kBlock / G) - 1) / (kBlock / G);
     if (lds > 64 * 1024)
-        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB, BF>, lds));
-    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB, BF>, kBlock, lds);
+        KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)agg_bwd_kernel<VEC, G, GCN, TAB, BF, GXACC>, lds));
+    const int nb = resident_blocks(agg_bwd_kernel<VEC, G, GCN, TAB, BF, GXACC>, kBlock, lds);
     const unsigned grid = pick_grid(tiles, nb > 0 ? nb : 4);
-    hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB, BF>), dim3(grid), dim3(kBlock), lds, s, p);
+    hipLaunchKernelGGL((agg_bwd_kernel<VEC, G, GCN, TAB, BF, GXACC>), dim3(grid), dim3(kBlock), lds, s, p);
     KPGNN_LAUNCH_CHECK("agg_bwd_kernel");
     return KPGNN_OK;
 }
@@ -657,6 +660,10 @@ int launch_bwd_mode(const BwdParams& p, int tab, size_t lds, hipStream_t s) {
             if (!gcn && tab == 0 && p.mode != KPGNN_MODE_GIN) return launch_bwd<VEC, G, false, 0, true>(p, 0, s);
         }
         return fail(KPGNN_EINVAL, "aggregate_bwd: bf16 storage needs mode GINPLUS/SUM without table gradients and D %% 4 == 0");
+    }
+    if (p.gx && p.acc_mask) {      // one [N,K,D] output that already holds part of the gradient: the chunked gather only
+        if (!gcn && tab == 0) return launch_bwd<VEC, G, false, 0, false, true>(p, 0, s);
+        return fail(KPGNN_EINVAL, "aggregate_bwd: accumulate_mask with gx needs a non-GCN mode without table gradients");
     }
     switch (tab) {
         case 0: return gcn ? launch_bwd<VEC, G, true, 0>(p, 0, s) : launch_bwd<VEC, G, false, 0>(p, 0, s);
@@ -801,7 +808,8 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         slot_bits |= (uintptr_t)p.gxs[k] & 15;
     }
     const void* slot_align = (const void*)(slot_bits | 16);
-    p.acc_mask = d->gx ? 0u : d->accumulate_mask;
+    p.acc_mask = d->accumulate_mask;      // (with gx: bit k adds hop k's gradient to what gx[:, k, :] already holds)
+    KPGNN_REQUIRE(d->accumulate_mask == 0 || d->K <= 32, "aggregate_bwd: accumulate_mask covers 32 hops");
     // (the kernel requests the old value of an accumulating slot one hop ahead and stores a hop's result one hop late:
     //  two hops of one launch must not share a slot buffer)
     for (int a = 0; a < d->K && a < 16; ++a)

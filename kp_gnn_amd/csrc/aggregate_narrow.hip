@@ -36,6 +36,7 @@ struct NarrowParams {
     int self_term;                 // 1: add (1 + eps) * (src[i,k,c] + xbias)   (GIN forward / backward)
     float* out; int64_t o_sn, o_sk;
     float* pre;
+    uint32_t acc_mask;             // bit k: out[:, k, :] += instead of =  (backward into a shared gradient buffer)
 };
 
 __device__ __forceinline__ float gelu_exact_n(float x) {
@@ -90,7 +91,9 @@ agg_narrow_kernel(const NarrowParams p) {
         if (p.periph) v += p.periph[(int64_t)i * p.p_sn + (int64_t)k * p.p_sk + c];
         else if (p.uid) v += p.ptab[(int64_t)p.uid[(int64_t)i * p.uid_stride + k] * D + c];
         if (p.self_term) v = fmaf(eps1, sk[(int64_t)i * p.s_sn] + xb, v);
-        p.out[(int64_t)i * p.o_sn + (int64_t)k * p.o_sk + c] = v;
+        float* dst = p.out + (int64_t)i * p.o_sn + (int64_t)k * p.o_sk + c;
+        if ((p.acc_mask >> k) & 1u) v += *dst;
+        *dst = v;
     }
 }
 
@@ -126,7 +129,7 @@ int agg_narrow_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled) {
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
     p.ptab = d->periph ? nullptr : d->ptab; p.uid = d->periph ? nullptr : d->uid; p.uid_stride = d->uid_stride;
     p.xbias = d->xbias; p.eps = d->eps; p.self_term = d->mode == KPGNN_MODE_GIN ? 1 : 0;
-    p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre;
+    p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.acc_mask = 0;
     *handled = true;
     return agg_narrow_launch(p, s);
 }
@@ -134,7 +137,7 @@ int agg_narrow_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled) {
 int agg_narrow_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled) {
     *handled = false;
     const bool want_tables = d->use_tables && d->gtable0;
-    if (d->D > 32 || !d->gx || d->mode == KPGNN_MODE_GCN || want_tables || d->storage != KPGNN_STORE_F32 ||
+    if (d->D > 32 || !d->gx || d->K > 32 || d->mode == KPGNN_MODE_GCN || want_tables || d->storage != KPGNN_STORE_F32 ||
         (int64_t)d->N * d->K * d->D > kNarrowMaxElems) return KPGNN_OK;
     NarrowParams p;
     p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.mode = KPGNN_MODE_SUM;   // (no activation on the way back)
@@ -145,7 +148,7 @@ int agg_narrow_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled) {
     p.table0 = p.tablek = nullptr;
     p.periph = nullptr; p.p_sn = p.p_sk = 0; p.ptab = nullptr; p.uid = nullptr; p.uid_stride = 0;
     p.xbias = nullptr; p.eps = d->eps; p.self_term = d->mode == KPGNN_MODE_GIN ? 1 : 0;
-    p.out = d->gx; p.o_sn = d->gx_sn; p.o_sk = d->gx_sk; p.pre = nullptr;
+    p.out = d->gx; p.o_sn = d->gx_sn; p.o_sk = d->gx_sk; p.pre = nullptr; p.acc_mask = d->accumulate_mask;
     *handled = true;
     return agg_narrow_launch(p, s);
 }

@@ -62,12 +62,17 @@ class KPGINConv(KHopMessagePassing, EdgeCodeTables):
 
     def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None):
         n = x.size(0)
+        state = x if (x.dim() == 2 and x.is_contiguous()) else None      # (the body's [N,H] state this layer reads)
         x = x.reshape(n, self.K, self.input_dk)
+        x3 = x
         csr, k_act = self._csr(edge_index, edge_attr, n)
         x, xbias = self._path_encoding(x, pe_attr)
         t0, tk = self._tables()
+        # (x_state: only when the aggregation reads the state itself - a live path encoding makes x a new tensor - and the
+        #  caller marked this layer as the state's last reader, see body.py)
+        share = state is not None and x is x3 and getattr(state, "_kp_last_reader", None) is self
         s = khop_aggregate(x, csr, k_act, MODE_GIN, table0=t0, tablek=tk, periph=peripheral_attr, eps=self.eps,
-                           xbias=xbias)                                  # N,K,dk = x_n + P + (1+eps) x
+                           xbias=xbias, x_state=state if share else None)   # N,K,dk = x_n + P + (1+eps) x
         if self._fused_mlp is None:
             geo = isinstance(self.combine, GeometricCombine)
             self._fused_mlp = 2 if (geo and hop_mlp_supported(self.K, self.input_dk, self.output_dk, self.output_size)) \

@@ -193,7 +193,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     return out, pre
 
 
-def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False, slot_bufs=None):
+def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False, slot_bufs=None, gx_accum=None):
     """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek); with slots=True gx is a list of
     k contiguous [N,D] tensors (one per hop slot) instead of one [N,k,D] tensor; slot_bufs[k] (a [N,D] tensor or None)
     makes the kernel ADD slot k's gradient into that buffer instead of writing a fresh one."""
@@ -235,6 +235,10 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
             d.gx_slot[k] = gx[k].data_ptr()
         d.gx_sn = sn
         d.accumulate_mask = mask
+    elif gx_accum is not None:     # the state's gradient cell ([N, K*D] contiguous): the kernel adds into it
+        gx = gx_accum.view(N, K, D)
+        d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
+        d.accumulate_mask = (1 << K) - 1
     else:
         gx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
         d.gx, d.gx_sn, d.gx_sk = gx.data_ptr(), gx.stride(0), gx.stride(1)
@@ -501,7 +505,10 @@ class KHopAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, cells, *xs):
-        ctx.cells = cells
+        # cells: per-hop inputs -> list of the slots' gradient cells; one [N,K,D] input -> the gradient cell of the STATE that x
+        # is a view of (or None): its other readers' gradients are then collected in one buffer (see khop_aggregate)
+        ctx.cells = cells if xs else None
+        ctx.x_cell = cells if (not xs and cells is not None) else None
         _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
         ctx.n_slots = len(xs)
         bf16 = False
@@ -645,8 +652,18 @@ class KHopAggregate(torch.autograd.Function):
                     raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
+        xbuf = None
+        if (ctx.x_cell is not None and ctx.x_cell.buf is not None and ctx.needs_input_grad[0] and k_act <= 32
+                and mode != MODE_GCN and not tables_in_gather):
+            b = ctx.x_cell.buf
+            if b.is_contiguous() and b.numel() == g.numel() and b.dtype == torch.float32:
+                xbuf = b
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
-                                       slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx))
+                                       slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx), gx_accum=xbuf)
+        if ctx.x_cell is not None:
+            if xbuf is None and ctx.x_cell.buf is not None and ctx.needs_input_grad[0]:
+                gx = gx + ctx.x_cell.buf.view_as(gx)     # (odd layout: add the parked share the plain way)
+            ctx.x_cell.buf = None
         if tables_in_gather:
             gt0, gtk = a0, ak
         if gtheta is not None and ctx.alphas is not None and not galphas_done:   # d/dalphas through theta (geo_theta.hip)
@@ -709,7 +726,7 @@ def _slot_grads(ctx, gx):
 
 
 def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, eps=None, theta=None, xbias=None,
-                   share_slot_grads=False):
+                   share_slot_grads=False, x_state=None):
     """x: [N,k,D] tensor, or a list/tuple of k per-hop [N,D] tensors (no stacking copy).
     periph: dense [N,k,D] tensor, a DictPeripheral, or None.
     theta: [k,D] hop weights of a fused combine, or the [D] `alphas` of a GeometricCombine (theta is then computed by the
@@ -732,7 +749,14 @@ def khop_aggregate(x, csr, k_act, mode, table0=None, tablek=None, periph=None, e
                     c = t._kp_slot_cell = _SlotGradCell()
                 cells.append(c)
         return KHopAggregate.apply(None, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, cells, *x)
-    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, None)
+    # x_state: the [N, K*D] state tensor that x is a view of, when the caller guarantees that this call is the LAST of the
+    # state's readers to run backward (the bodies: the jumping-knowledge projection and the next norm's residual branch read
+    # it too, both later in the forward).  Those readers park their share of d/dstate in the state's cell and the gather
+    # kernel adds its own into the same buffer - no [N,H] tensors for autograd to sum.
+    cell = None
+    if x_state is not None and torch.is_grad_enabled() and x_state.requires_grad and x_state.is_cuda:
+        cell = state_cell(x_state)
+    return KHopAggregate.apply(x, table0, tablek, periph, eps, theta, xbias, ptab, csr, k_act, mode, uid, cell)
 
 
 class DictRows(torch.autograd.Function):
