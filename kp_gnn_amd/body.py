@@ -490,10 +490,13 @@ class GNNPrime(_KHopBody):
         for l in range(self.num_layer):
             if self.virtual_node:
                 h_list[l] = h_list[l] + vn[batch]
+            layer = self.khop_gnns[l] if l < self.num_l1_layer else self.gins[l - self.num_l1_layer]
+            if h_list[l].is_cuda:
+                h_list[l]._kp_last_reader = layer       # (as in GNN.forward: the norm's residual and the JK projection come later)
             if l < self.num_l1_layer:
-                h = self.khop_gnns[l](h_list[l], edge_index, edge_attr, pe_attr, periph)
+                h = layer(h_list[l], edge_index, edge_attr, pe_attr, periph)
             else:
-                h = self.gins[l - self.num_l1_layer](h_list[l], edge_index, edge_attr[:, :1])
+                h = layer(h_list[l], edge_index, edge_attr[:, :1])
             drops = l < self.num_l1_layer or l != self.num_layer - 1   # (:659 drops out after every K-hop layer)
             fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or not drops)
             h = self.norms[l](h, residual=h_list[l] if fuse_res else None)

@@ -38,6 +38,8 @@ class GINEConv(KHopMessagePassing):
     def forward(self, x, edge_index, edge_attr):
         n = x.size(0)
         csr, k_act = get_khop_csr(edge_index, edge_attr, n)
+        # (x_state: the body marked this layer as the LAST of the state's readers to run backward - ops.khop_aggregate)
+        share = x.dim() == 2 and x.is_contiguous() and getattr(x, "_kp_last_reader", None) is self
         out = khop_aggregate(x.reshape(n, 1, self.input_size), csr, k_act, MODE_GIN,
-                             table0=self.hop1_edge_emb.weight, eps=self.eps)
+                             table0=self.hop1_edge_emb.weight, eps=self.eps, x_state=x if share else None)
         return mlp_linear_bn_relu_x2(self.mlp, out.squeeze(1), emit_out_stats=getattr(self, "_kp_emit_out_stats", False))
