@@ -80,7 +80,9 @@ template <> struct Cols<2> {
 // epilogue  g = theta[k] * gh[i] * gelu'(S[i,k])  (kpgnn_combine_bwd's arithmetic): wave w owns hop w, reads its 8 rows of S
 // (one 416-byte row per request, next tile's rows in flight), writes them to g AND to the LDS tile, and keeps the theta
 // gradient of its hop in two registers for the whole launch.  g is then never read back for the table gradients.
-template <int CPL, bool VEC4, bool BF = false, bool FUSE = false>
+// WPH1 (FUSE): K >= 5, one wave per hop - the node stride of the compute phase is then a compile-time 1 (with the run-time
+// stride the k = 8 launch took 132 instead of 126 us).
+template <int CPL, bool VEC4, bool BF = false, bool FUSE = false, bool WPH1 = false>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // (HIP: waves per SIMD) two blocks per CU: 128 VGPRs
 table_grad_kernel(const TgParams p, int AS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -146,7 +148,7 @@ table_grad_kernel(const TgParams p, int AS) {
     };
     if (FUSE) {
         int kp = 1; while (kp < K) kp <<= 1;
-        const int wph0 = kWavesTG / kp;
+        const int wph0 = WPH1 ? 1 : kWavesTG / kp;
         load_s_rows(blockIdx.x, w / wph0, w % wph0, wph0);
     } else if (VEC4) {
 #pragma unroll
@@ -185,7 +187,7 @@ table_grad_kernel(const TgParams p, int AS) {
         m.fu = 0;                                     // FUSE: lane n < 8: dictionary id of (node n of tile t2, this wave's hop)
         if (FUSE && p.f_uid && lane < p.NT && t2 < num_tiles && t2 * p.NT + lane < p.N) {
             int kp = 1; while (kp < K) kp <<= 1;
-            const int k2 = w / (kWavesTG / kp);
+            const int k2 = WPH1 ? w : w / (kWavesTG / kp);
             if (k2 < K) m.fu = p.f_uid[(t2 * p.NT + lane) * p.f_uid_stride + k2];
         }
     };
@@ -199,7 +201,7 @@ table_grad_kernel(const TgParams p, int AS) {
     // FUSE: wave w computes hop fk for the nodes n = fsub, fsub + wph, ... of a tile; with K <= 4 hops several waves share a
     // hop (wph = 8 / pow2ceil(K)) so that the compute phase keeps all waves busy for the early layers too
     int wph = 1;
-    if (FUSE) { int kp = 1; while (kp < K) kp <<= 1; wph = kWavesTG / kp; }
+    if (FUSE && !WPH1) { int kp = 1; while (kp < K) kp <<= 1; wph = kWavesTG / kp; }
     const int fk = w / wph, fsub = w - fk * wph;
     const bool fwave = FUSE && fk < K;
     int gbuf = 0;                                     // FUSE: ghs buffer that holds the CURRENT tile's gh rows
@@ -619,10 +621,10 @@ int make_plan(int N, int K, int D, int NT, int n0, int nk, int U, Plan* pl, int 
     return KPGNN_OK;
 }
 
-template <int CPL, bool VEC4, bool BF = false, bool FUSE = false>
+template <int CPL, bool VEC4, bool BF = false, bool FUSE = false, bool WPH1 = false>
 int launch_walk(const TgParams& p, const Plan& pl, hipStream_t s) {
-    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4, BF, FUSE>, pl.lds));
-    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4, BF, FUSE>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)table_grad_kernel<CPL, VEC4, BF, FUSE, WPH1>, pl.lds));
+    hipLaunchKernelGGL((table_grad_kernel<CPL, VEC4, BF, FUSE, WPH1>), dim3(pl.grid_x, pl.grid_y), dim3(kThreadsTG), pl.lds, s, p, pl.AS);
     KPGNN_LAUNCH_CHECK("table_grad_kernel");
     return KPGNN_OK;
 }
@@ -703,7 +705,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
                       (size_t)d->workspace_bytes, pl.ws_bytes);
         p.slab = (float*)d->workspace;
-        rc = launch_walk<2, false, false, true>(p, pl, s);
+        rc = p.K >= 5 ? launch_walk<2, false, false, true, true>(p, pl, s) : launch_walk<2, false, false, true, false>(p, pl, s);
         if (rc != KPGNN_OK) return rc;
         ThetaFinish tf;
         tf.slab = nullptr; tf.nslab = 0; tf.alpha = d->fuse_alphas; tf.theta = d->theta; tf.K = d->K; tf.D = d->D;
