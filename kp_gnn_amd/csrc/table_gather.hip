@@ -125,29 +125,71 @@ tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
                 const int64_t n = (m1 - mm < RT ? m1 - mm : RT) * C;
                 return (mm < m1 && lane < n) ? (int)p.idx[mm * C + lane] : 0;
             };
-            float g[4], ng[4];
             auto load_g = [&](int64_t mm, float* o) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[u] = (u < RT && mm + u < m1 && col_ok) ? p.gout[(mm + u) * p.gout_stride + col_base + col] : 0.f;
             };
-            int idxv = load_idx(m0);
-            load_g(m0, g);
-            for (int64_t m = m0; m < m1; m += RT) {
-                const int nidx = load_idx(m + RT);
-                load_g(m + RT, ng);
-                const int nrows = (int)(m1 - m < RT ? m1 - m : RT);
-                for (int c = 0; c < C; ++c) {
-                    const int off = __builtin_amdgcn_readlane(offv, c);
+            constexpr int kRunC = 16;
+            int cur[kRunC]; float run[kRunC];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < nrows) {
-                            const int row = off + __builtin_amdgcn_readlane(idxv, u * C + c);
-                            if (col_ok) atomicAdd(acc + row * CW, g[u]);   // ds_add_f32, no return: see the header
+            for (int c = 0; c < kRunC; ++c) { cur[c] = -1; run[c] = 0.f; }
+            // Four batches of RT rows are in flight: with ONE wave per group and one group per block (the accumulator table
+            // fills the LDS) nothing else hides the ~2 us of a global round trip - a batch requested one batch ahead made
+            // every batch wait for it (1.7 ms per launch on the dense peripheral tensors).
+            constexpr int PD = 4;
+            int iq[PD]; float gq[PD][4];
+#pragma unroll
+            for (int b = 0; b < PD; ++b) { iq[b] = load_idx(m0 + (int64_t)b * RT); load_g(m0 + (int64_t)b * RT, gq[b]); }
+            for (int64_t mb = m0; mb < m1; mb += (int64_t)PD * RT) {
+#pragma unroll
+                for (int b = 0; b < PD; ++b) {
+                    const int64_t m = mb + (int64_t)b * RT;
+                    const int idxv = iq[b];
+                    float g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[u] = gq[b][u];
+                    iq[b] = load_idx(m + (int64_t)PD * RT);
+                    load_g(m + (int64_t)PD * RT, gq[b]);
+                    if (m >= m1) continue;
+                    const int nrows = (int)(m1 - m < RT ? m1 - m : RT);
+                    if (C <= kRunC) {
+                        // Consecutive rows mostly carry the SAME index in a component (94 % on the peripheral tensors of a
+                        // molecule batch: most slots are the "none" code), and an LDS float add costs ~150 cycles of the CU's
+                        // LDS pipe: per component the run of equal rows is summed in a register and added once when the
+                        // index changes.  cur[] are wave-uniform (scalar registers), the component loop is unrolled.
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (u < nrows) {
+#pragma unroll
+                                for (int c = 0; c < kRunC; ++c) {
+                                    if (c < C) {
+                                        const int row = __builtin_amdgcn_readlane(offv, c) + __builtin_amdgcn_readlane(idxv, u * C + c);
+                                        if (row != cur[c]) {
+                                            if (cur[c] >= 0 && col_ok) atomicAdd(acc + cur[c] * CW, run[c]);
+                                            cur[c] = row;
+                                            run[c] = 0.f;
+                                        }
+                                        run[c] += g[u];
+                                    }
+                                }
+                            }
                         }
-                }
-                idxv = nidx;
+                    } else
+                    for (int c = 0; c < C; ++c) {
+                        const int off = __builtin_amdgcn_readlane(offv, c);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = ng[u];
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nrows) {
+                                const int row = off + __builtin_amdgcn_readlane(idxv, u * C + c);
+                                if (col_ok) atomicAdd(acc + row * CW, g[u]);   // ds_add_f32, no return: see the header
+                            }
+                    }
+                }
+            }
+            if (C <= kRunC) {
+#pragma unroll
+                for (int c = 0; c < kRunC; ++c)
+                    if (c < C && cur[c] >= 0 && col_ok) atomicAdd(acc + cur[c] * CW, run[c]);
             }
         } else if (col_ok) {
             // four rows per trip: their loads are independent of the LDS adds of the previous rows
