@@ -98,13 +98,18 @@ tgs_kernel(const TgsParams p) {
 // (ds_add_f32) all the same: a plain `+=` is a load-add-store chain that waits for the LDS latency at every index, while
 // the fire-and-forget form keeps the LDS pipeline full and stays ordered per address within a wave.
 __global__ void __launch_bounds__(kBlock)
-tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
+tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab, int csplit) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [NG][R][CW]
     const int Ds = p.Ds, R = p.R;
     const int col_base = blockIdx.y * Ds;
     for (int t = threadIdx.x; t < NG * R * CW; t += kBlock) lds[t] = 0.f;
     __syncthreads();
-    const int grp = threadIdx.x / CW, col = threadIdx.x % CW;
+    // csplit (one table per block, CW == 64): ALL waves of the block walk the block's rows, each for ITS components - the
+    // components of different waves address disjoint table rows (components that share a table, i.e. an offset, stay
+    // together), so the waves share the one accumulator table without ever touching the same cell: four waves instead of
+    // one on the scalar chain that bounds this kernel, same fixed order of every sum.
+    const int grp = csplit ? 0 : threadIdx.x / CW, col = threadIdx.x % CW;
+    const int wv = threadIdx.x / kWave, nwv = kBlock / kWave;
     const int64_t per_block = (p.M + gridDim.x - 1) / gridDim.x;
     const int64_t b0 = (int64_t)blockIdx.x * per_block;
     const int64_t b1 = b0 + per_block < p.M ? b0 + per_block : p.M;
@@ -121,6 +126,34 @@ tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
             const int lane = threadIdx.x & (kWave - 1);
             const int C = p.C, RT = min(4, kWave / C);
             const int offv = lane < C ? p.col_offset[lane] : 0;
+            unsigned long long mycomps = ~0ull;                  // components this wave handles
+            if (csplit) {
+                // distinct tables (offsets) are dealt to the waves longest-first onto the least loaded wave: a table used by m
+                // components costs m items per row
+                bool first = true;                               // no earlier component has my offset
+                int mult = 0;                                    // components with my offset
+                for (int j = 0; j < C; ++j) {
+                    const int oj = __builtin_amdgcn_readlane(offv, j);
+                    if (oj == offv) { ++mult; if (j < lane) first = false; }
+                }
+                unsigned long long todo = __ballot(lane < C && first);
+                int wload[4] = {0, 0, 0, 0};
+                int mywave = -1;
+                while (todo) {
+                    int best = -1, bm = -1;
+                    for (unsigned long long t = todo; t; t &= t - 1) {
+                        const int j = (int)__builtin_ctzll(t);
+                        const int m = __builtin_amdgcn_readlane(mult, j);
+                        if (m > bm) { bm = m; best = j; }
+                    }
+                    int wmin = 0;
+                    for (int q = 1; q < nwv && q < 4; ++q) if (wload[q] < wload[wmin]) wmin = q;
+                    wload[wmin] += bm;
+                    if (offv == __builtin_amdgcn_readlane(offv, best)) mywave = wmin;
+                    todo &= ~(1ull << best);
+                }
+                mycomps = __ballot(lane < C && mywave == wv);
+            }
             auto load_idx = [&](int64_t mm) -> int {
                 const int64_t n = (m1 - mm < RT ? m1 - mm : RT) * C;
                 return (mm < m1 && lane < n) ? (int)p.idx[mm * C + lane] : 0;
@@ -162,7 +195,7 @@ tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
                             if (u < nrows) {
 #pragma unroll
                                 for (int c = 0; c < kRunC; ++c) {
-                                    if (c < C) {
+                                    if (c < C && ((mycomps >> c) & 1ull)) {
                                         const int row = __builtin_amdgcn_readlane(offv, c) + __builtin_amdgcn_readlane(idxv, u * C + c);
                                         if (row != cur[c]) {
                                             if (cur[c] >= 0 && col_ok) atomicAdd(acc + cur[c] * CW, run[c]);
@@ -189,7 +222,7 @@ tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab) {
             if (C <= kRunC) {
 #pragma unroll
                 for (int c = 0; c < kRunC; ++c)
-                    if (c < C && cur[c] >= 0 && col_ok) atomicAdd(acc + cur[c] * CW, run[c]);
+                    if (c < C && ((mycomps >> c) & 1ull) && cur[c] >= 0 && col_ok) atomicAdd(acc + cur[c] * CW, run[c]);
             }
         } else if (col_ok) {
             // four rows per trip: their loads are independent of the LDS adds of the previous rows
@@ -279,7 +312,8 @@ int run_bwd(const kpgnn_tgs_desc* d, hipStream_t s) {
     p.table = nullptr; p.bias = nullptr; p.out = nullptr; p.out_stride = 0;
     p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
     KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_bwd_kernel, pl.lds));
-    hipLaunchKernelGGL(tgs_bwd_kernel, dim3(pl.gx, pl.splits), dim3(kBlock), pl.lds, s, p, pl.CW, pl.NG, (float*)d->workspace);
+    const int csplit = (pl.NG == 1 && pl.CW == kWave && d->C <= 16 && d->C >= 2) ? 1 : 0;
+    hipLaunchKernelGGL(tgs_bwd_kernel, dim3(pl.gx, pl.splits), dim3(kBlock), pl.lds, s, p, pl.CW, pl.NG, (float*)d->workspace, csplit);
     KPGNN_LAUNCH_CHECK("tgs_bwd_kernel");
     return slab_reduce((const float*)d->workspace, pl.gx, (int64_t)d->R * d->D, d->gtable, (int64_t)d->R * d->D, nullptr, 0, nullptr, s);
 }
