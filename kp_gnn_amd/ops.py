@@ -372,10 +372,14 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
     return gt0, gtk, gd
 
 
-def _combine_table_grad_ok(csr, pre):
+def _combine_table_grad_ok(csr, pre, table_rows=0, dict_rows=0):
+    """Shapes the fused combine + table-gradient kernel takes (kpgnn_table_grad with fuse_pre): fp32, K <= 8, even D <= 128,
+    tiles of 8 nodes, and an LDS plan that fits - tile + (table rows + dictionary rows + 40 service rows) * D floats
+    <= 160 KB (e.g. train_SR.py's max_pe_num = 1000 does not: those layers keep the separate kernels)."""
     N, K, D = pre.shape
+    lds = 4 * (8 * K * D + (table_rows + 2 * dict_rows + 40) * D) + 64
     return (pre.dtype == torch.float32 and K <= 8 and D % 2 == 0 and D <= 128 and csr.nodes_per_tile == 8
-            and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0)
+            and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0 and lds <= 160 * 1024)
 
 
 def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None,
@@ -389,9 +393,9 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
     lib = _lib.load()
     N, K, D = pre.shape
     dev = pre.device
-    if not _combine_table_grad_ok(csr, pre):
-        return None
     nk = n_codek if K > 1 else 0
+    if not _combine_table_grad_ok(csr, pre, n_code0 + nk, ptab.shape[0] if (ptab is not None and uid is not None) else 0):
+        return None
     gd = None
     if dict_rows > 0:
         pack, kf = dict_tile_pack(csr, uid)
@@ -578,7 +582,7 @@ class KHopAggregate(torch.autograd.Function):
         #     gh, writes it for the gather below and takes the table gradients from the LDS copy of each tile; the dictionary
         #     gradient comes from gh alone (dict_grad), its partial sums added up by the same finishing launch
         if (fused and mode == MODE_GINPLUS and want_tables and periph is None and not want_gperiph
-                and _combine_table_grad_ok(csr, pre)):
+                and _combine_table_grad_ok(csr, pre, ctx.n_code0 + (ctx.n_codek if k_act > 1 else 0), ctx.n_dict)):
             extra = dg = None
             if want_gdict and pre.shape[0] >= 4096:
                 dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)

@@ -1036,6 +1036,56 @@ def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk)
         _close(r[4], t_ref[2].cpu(), "gdict", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("nk", [12, 1002])
+def test_fused_backward_path_equals_separate_path_end_to_end(nk, monkeypatch):
+    """khop_aggregate (KP-GIN+ epilogue, geometric combine, dictionary P) backward through the fused combine + table-gradient
+    kernel against the same call with that kernel disabled (combine_bwd + table_grad + ...): all gradients agree.  nk = 1002
+    (train_SR.py's max_pe_num = 1000) does not fit the fused kernel's LDS plan: both runs then take the separate kernels and
+    nothing raises."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    N, E, K, D, U = 700, 9000, 6, 104, 9
+    g0 = torch.Generator().manual_seed(nk)
+    ei = torch.randint(0, N, (2, E), generator=g0)
+    ea = torch.zeros(E, K, dtype=torch.long)
+    act = torch.rand(E, K, generator=g0) < 0.4
+    ea[:, 0] = torch.randint(1, 5, (E,), generator=g0) * act[:, 0]
+    ea[:, 1:] = torch.randint(1, nk, (E, K - 1), generator=g0) * act[:, 1:]
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    base = dict(xs=[torch.randn(N, D, generator=g0) for _ in range(K)], t0=torch.randn(5, D, generator=g0) * 0.3,
+                tk=torch.randn(nk, D, generator=g0) * 0.3, ptab=torch.randn(U, D, generator=g0), alphas=torch.randn(D, generator=g0))
+    uid = torch.randint(0, U, (N, K), generator=g0, dtype=torch.int32).to(dev)
+    w = torch.randn(N, D, generator=g0).to(dev)
+    used = []
+    real = ops.combine_table_grad_raw
+
+    def spy(*a, **kw):
+        r = real(*a, **kw)
+        used.append(r is not None)
+        return r
+
+    monkeypatch.setattr(ops, "combine_table_grad_raw", spy)
+
+    def run():
+        t = {k: ([x.clone().to(dev).requires_grad_(True) for x in v] if isinstance(v, list) else v.clone().to(dev).requires_grad_(True))
+             for k, v in base.items()}
+        out = ops.khop_aggregate(t["xs"], csr, K, ops.MODE_GINPLUS, t["t0"], t["tk"], ops.DictPeripheral(t["ptab"], uid),
+                                 theta=t["alphas"])
+        (out * w).sum().backward()
+        return t
+
+    a = run()
+    fused_ran = any(used)
+    assert fused_ran == (nk == 12), (nk, used)
+    monkeypatch.setattr(ops, "_combine_table_grad_ok", lambda *args, **kw: False)
+    b = run()
+    for k in ("t0", "tk", "ptab", "alphas"):
+        _close(a[k].grad, b[k].grad.cpu(), "grad " + k, rtol=2e-4, atol=2e-5)
+    for k in range(K):
+        _close(a["xs"][k].grad, b["xs"][k].grad.cpu(), f"grad xs[{k}]", rtol=1e-5, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------- hipGraph capture: replay == eager
 def _small_body(model_name, combine, K, L, H):
     import argparse
