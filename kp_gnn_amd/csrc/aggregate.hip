@@ -718,7 +718,9 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     }
     {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
         bool handled = false;
-        const int rc = agg_narrow_fwd(d, (hipStream_t)stream, &handled);
+        int rc = agg_narrow_fwd(d, (hipStream_t)stream, &handled);
+        if (rc != KPGNN_OK || handled) return rc;
+        rc = agg_small_fwd(d, (hipStream_t)stream, &handled);      // small batches: all hops of a node at once
         if (rc != KPGNN_OK || handled) return rc;
     }
     FwdParams p;
@@ -816,6 +818,11 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
         for (int b = a + 1; b < d->K && b < 16; ++b)
             if (p.gxs[a] && p.gxs[a] == p.gxs[b] && (((p.acc_mask >> a) | (p.acc_mask >> b)) & 1u))
                 return fail(KPGNN_EINVAL, "aggregate_bwd: hop slots %d and %d share one gradient buffer with accumulate_mask set", a, b);
+    {   // small batches: one block per node, all hops at once (aggregate_small.hip)
+        bool handled = false;
+        const int rc = agg_small_bwd(d, (hipStream_t)stream, &handled);
+        if (rc != KPGNN_OK || handled) return rc;
+    }
     if ((uint64_t)d->N * (uint64_t)d->g_sn * 4u >= (1ull << 32))
         return fail(KPGNN_ELIMIT, "aggregate_bwd: N * g row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->g_sn);
     const int vec = pick_vec(d->D, {d->g, d->gx ? (const void*)d->gx : slot_align}, {d->g_sn, d->g_sk, d->gx_sn, d->gx ? d->gx_sk : 0});

@@ -135,6 +135,9 @@ size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int
 // Element-per-thread aggregation for narrow rows (aggregate_narrow.hip): *handled tells whether the launch was done.
 int agg_narrow_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled);
 int agg_narrow_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled);
+// One block per node, one unit per hop, for small batches (aggregate_small.hip): *handled as above.
+int agg_small_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled);
+int agg_small_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled);
 
 // erf(z) by Abramowitz-Stegun 7.1.26 (max abs error 5.4e-7 in fp32 over [-6,6]; exact +-1 beyond): ~14 VALU ops
 // against ~30 for libm's erff, which made the GELU epilogue VALU-bound (28 us of a 160 us launch).  Also
