@@ -104,14 +104,20 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p) {
 template <int TI>
 __global__ void __launch_bounds__(512)
 wgrad_kernel(const WgPair pp, int nprob) {
+    if (gridDim.y > 1) {       // small batches: the two problems side by side (a block's serial chain is what a launch costs there)
+        if (blockIdx.y == 0) wgrad_problem<TI>(pp.q[0]);
+        else wgrad_problem<TI>(pp.q[1]);
+        return;
+    }
     wgrad_problem<TI>(pp.q[0]);
     if (nprob > 1) wgrad_problem<TI>(pp.q[1]);
 }
 
 // Blocks of a launch: every block writes a full O x I partial to the slab, so a small batch must not spread its few rows
-// over 512 blocks (N = 1.5k: 44 MB of slab written and re-read for 1.2 MB of operands); >= 32 rows per block.
+// over 512 blocks (N = 1.5k: 44 MB of slab written and re-read for 1.2 MB of operands); >= 16 rows per block (32 measured
+// 1.27 against 1.26 ms per batch-64 step: the shorter per-block chain is worth the larger slab).
 int wgrad_grid(int64_t N) {
-    int64_t g = (N + 31) / 32;
+    int64_t g = (N + 15) / 16;
     if (g > kWgradBlocks) g = kWgradBlocks;
     return (int)(g < 1 ? 1 : g);
 }
@@ -135,7 +141,9 @@ WgParams wgrad_params(const kpgnn_wgrad_desc* d, float* slab, int64_t slab_row, 
 
 int wgrad_launch(const WgPair& pp, int nprob, int O, int I, int grid, hipStream_t s) {
     const int waves = (O + 31) / 32, ti = (I + 31) / 32;
-    dim3 blk(waves * 64), gr(grid);
+    // (two problems: one after the other on the same grid when the grid fills the chip - side by side they measured 94 us
+    //  against 2 x 28 - but side by side when there are only a few dozen blocks)
+    dim3 blk(waves * 64), gr(grid, (nprob > 1 && grid <= 128) ? 2 : 1);
     switch (ti) {
         case 1: hipLaunchKernelGGL(wgrad_kernel<1>, gr, blk, 0, s, pp, nprob); break;
         case 2: hipLaunchKernelGGL(wgrad_kernel<2>, gr, blk, 0, s, pp, nprob); break;
