@@ -70,6 +70,8 @@ agg_fwd_small_kernel(const SmallFwd p) {
     for (int64_t i = blockIdx.x; i < p.N; i += gridDim.x) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         int seglen = 0;
+        float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);               // the dictionary row: requested up front (uid -> row is its own chain)
+        if (hop_ok && col_ok) pr = *reinterpret_cast<const float4*>(p.ptab + (int64_t)p.uid[i * p.uid_stride + k] * D + c0);
         if (hop_ok) {
             const int32_t* rp = p.rowptr + i * p.K_csr + k;
             const int beg = rp[0], end = rp[1];
@@ -114,7 +116,6 @@ agg_fwd_small_kernel(const SmallFwd p) {
                 v[0] = fmaf(sl_f, xb.x, v[0]); v[1] = fmaf(sl_f, xb.y, v[1]); v[2] = fmaf(sl_f, xb.z, v[2]); v[3] = fmaf(sl_f, xb.w, v[3]);
             }
             *reinterpret_cast<float4*>(p.pre + (i * p.K + k) * (int64_t)D + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            const float4 pr = *reinterpret_cast<const float4*>(p.ptab + (int64_t)p.uid[i * p.uid_stride + k] * D + c0);
             o[0] = th[0] * (gelu_exact_s(v[0]) + pr.x); o[1] = th[1] * (gelu_exact_s(v[1]) + pr.y);
             o[2] = th[2] * (gelu_exact_s(v[2]) + pr.z); o[3] = th[3] * (gelu_exact_s(v[3]) + pr.w);
         }
