@@ -104,7 +104,7 @@ def fwd_bwd(args, model, batch, flat_grad):
     params, views = dp.grad_views(model)
     grads = torch.autograd.grad(loss, params, allow_unused=True)
     used = [(v, g) for v, g in zip(views, grads) if g is not None]
-    torch._foreach_copy_([v for v, _ in used], [g for _, g in used])
+    dp.copy_grads([v for v, _ in used], [g for _, g in used])
     # (parameters without a gradient - e.g. the never-trained path-encoding tables, Q1 - keep the zeros the flat bucket
     #  was created with: nothing ever writes their views)
     return loss

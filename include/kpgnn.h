@@ -90,6 +90,12 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
 int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t k,
                            int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
 
+/* count contiguous fp32 tensors copied device-to-device in ceil(count / 96) launches: dst[i][0..numel[i]) = src[i][..].  The
+ * pointer tables are HOST arrays read at call time and passed to the kernel by value (capturable: a hipGraph node keeps
+ * them).  Used to move a step's parameter gradients into their views of the flat all-reduce bucket (train_ZINC.py:34-36
+ * leaves that to DataParallel's per-tensor reduce). */
+int kpgnn_multi_copy(int32_t count, const float* const* src, float* const* dst, const int64_t* numel, kpgnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
  * ---------------------------------------------------------------------------------------------- */
@@ -398,6 +404,11 @@ typedef struct kpgnn_bn_bwd_desc {
     /* Optional, for z = bn(x) + residual: the residual branch's gradient (= dz) is ADDED in place to this [N,C]
      * buffer by the apply pass (a state read by several layers collects its gradient in one buffer). */
     float* residual_grad; int64_t rg_stride;
+    /* Optional, with reduce_only: the STACKED reduce for  x -> z = [relu](bn(x)) -> h = bn_outer(z) (+ residual)  with dz
+     * the gradient of h.  outer_mean / outer_invstd [C] are the outer norm's batch statistics (of z); stat_slot is then
+     * 4 * kpgnn_stat_slot_bytes(C) (eight column sums, see bn.hip) and is consumed by kpgnn_linear_bn with pro = 3, which
+     * applies both norms' backward while it loads its tile.  residual_grad (if set) still receives += dz. */
+    const float* outer_mean; const float* outer_invstd;
 } kpgnn_bn_bwd_desc;
 
 int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);
@@ -478,6 +489,10 @@ int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
  *          statistics, in_slot holds (sum dzm, sum dzm*xhat) (kpgnn_bn_bwd reduce_only, or epi 2 of the previous
  *          launch); the tile becomes dy = gamma*invstd*(dzm - s0/N - xhat*s1/N) with dzm = dz * [bn(x2) > 0 if
  *          pro_relu]; dy is also written to xt (the weight-gradient kernel reads it); dgamma / dbeta are written.
+ *   pro 3: TWO stacked BatchNorms' backward on load, for  x2 -> z = [pro_relu](bn_in(x2)) -> h = bn_o(z) (+ residual):
+ *          x is dh, in_slot the eight sums of kpgnn_bn_bwd's stacked reduce (outer_mean set), in_* the inner norm, o_mean /
+ *          o_invstd / o_gamma the outer one; dz is formed in registers (never stored), the tile becomes the inner norm's
+ *          dy as in pro 2 (also written to xt); dgamma / dbeta and o_dgamma / o_dbeta are written.  Only with epi 2.
  *   epi 0: y stored as is.
  *   epi 1: + (sum y, sum y^2) per column into out_slot.
  *   epi 2: y is masked by the ReLU of the BatchNorm whose input was e_x (y = 0 where bn_e(e_x) <= 0) and
@@ -498,6 +513,7 @@ typedef struct kpgnn_linear_bn_desc {
     const float* x2; float* xt; float* dgamma; float* dbeta;
     double* out_slot;
     const float* e_x; const float* e_mean; const float* e_invstd; const float* e_gamma; const float* e_beta;
+    const float* o_mean; const float* o_invstd; const float* o_gamma; float* o_dgamma; float* o_dbeta;   /* pro 3 */
 } kpgnn_linear_bn_desc;
 
 int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t stream);

@@ -100,6 +100,7 @@ class BnBwdDesc(ctypes.Structure):
         ("gamma", c_vp), ("beta", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("dx", c_vp), ("dx_stride", c_i64), ("dgamma", c_vp), ("dbeta", c_vp),
         ("stat_slot", c_vp), ("reduce_only", c_i32), ("residual_grad", c_vp), ("rg_stride", c_i64),
+        ("outer_mean", c_vp), ("outer_invstd", c_vp),
     ]
 
 
@@ -124,6 +125,7 @@ class LinearBnDesc(ctypes.Structure):
         ("x2", c_vp), ("xt", c_vp), ("dgamma", c_vp), ("dbeta", c_vp),
         ("out_slot", c_vp),
         ("e_x", c_vp), ("e_mean", c_vp), ("e_invstd", c_vp), ("e_gamma", c_vp), ("e_beta", c_vp),
+        ("o_mean", c_vp), ("o_invstd", c_vp), ("o_gamma", c_vp), ("o_dgamma", c_vp), ("o_dbeta", c_vp),
     ]
 
 
@@ -200,6 +202,7 @@ SIGNATURES = {
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "kpgnn_multi_copy": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),
     "kpgnn_combine_bwd": (ctypes.c_int, [ctypes.POINTER(CombineBwdDesc), c_vp]),

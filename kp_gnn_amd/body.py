@@ -435,13 +435,20 @@ class GNNPlus(_KHopBody):
             k = min(l + 1, self.K)
             slots = [h_list[l - m] for m in range(k)]                  # slot m = state of layer l-m
             pek = pe_attr[:, :k - 1] if pe_attr is not None else None
+            fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
+            res = last_h if fuse_res else None
             if hasattr(self.gnns[l], "forward_slots") and slots[0].is_cuda:
-                # (history=True: slot m is the state of layer l-m, so the layers may pool their slot gradients per state)
-                h = self.gnns[l].forward_slots(slots, edge_index, edge_attr[:, :k], pek, periph[:, :k], history=True)
+                # (history=True: slot m is the state of layer l-m, so the layers may pool their slot gradients per state;
+                #  post_norm: norms[l] (+ residual) is applied by the layer's own last autograd node, see ops_dense.FusedMLP)
+                norm = self.norms[l]
+                post = (norm.module, res) if isinstance(norm, BatchNorm) else None
+                h = self.gnns[l].forward_slots(slots, edge_index, edge_attr[:, :k], pek, periph[:, :k], history=True,
+                                               post_norm=post)
+                if post is None:
+                    h = norm(h, residual=res)
             else:
                 h = self.gnns[l](torch.stack(slots, dim=1), edge_index, edge_attr[:, :k], pek, periph[:, :k])
-            fuse_res = self.residual and (self.dropout.p == 0.0 or not self.training or l == self.num_layer - 1)
-            h = self.norms[l](h, residual=last_h if fuse_res else None)   # norm (+ residual) in one pass
+                h = self.norms[l](h, residual=res)   # norm (+ residual) in one pass
             if l != self.num_layer - 1:
                 h = self.dropout(h)
             if self.residual:

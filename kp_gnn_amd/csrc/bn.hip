@@ -44,6 +44,7 @@ struct BnParams {
     double* out_slot;                  // producer side
     float* dgamma; float* dbeta;
     float* racc; int64_t racs;         // bwd apply: racc[r,:] += dz[r,:] (the residual branch's gradient, accumulated in place)
+    const float* o_mean; const float* o_invstd;   // stacked reduce: the OUTER BatchNorm's statistics
 };
 
 __device__ __forceinline__ double slot_sum(const double* slot, int C, int which, int c) {
@@ -70,6 +71,27 @@ __device__ __forceinline__ void block_to_slot(double* slot, int C, const double 
         }
     }
     (void)c0; (void)col_ok;
+}
+
+// The same for NS statistics (NS even), two at a time through the same LDS: slot = double[replica][NS][C].
+template <int VEC, int G, int NS>
+__device__ __forceinline__ void block_to_slot_n(double* slot, int C, const double (&acc)[NS][VEC]) {
+    __shared__ double red[2][kBlock / G][G * VEC];
+    const int rl = threadIdx.x / G, sl = threadIdx.x % G;
+#pragma unroll
+    for (int pr = 0; pr < NS; pr += 2) {
+        for (int q = 0; q < VEC; ++q) { red[0][rl][sl * VEC + q] = acc[pr][q]; red[1][rl][sl * VEC + q] = acc[pr + 1][q]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * G * VEC; t += kBlock) {
+            const int which = t / (G * VEC), col = t - which * (G * VEC);
+            if (col < C) {
+                double s = 0.0;
+                for (int r = 0; r < kBlock / G; ++r) s += red[which][r][col];
+                atomicAdd(slot + ((int64_t)(blockIdx.x % KPGNN_STAT_REPLICAS) * NS + pr + which) * C + col, s);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // fwd stats: sum x, sum x^2 (fp64: no pivot needed)
@@ -193,6 +215,73 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p)
         }
     }
     block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
+}
+
+// Stacked backward reduce: y -> z = [relu](bn_in(y)) -> h = bn_out(z) (+ residual), incoming gradient dh.  ONE pass over
+// (dh, y) leaves the eight column sums from which the consumer (lin_fused.h, PRO 3) finishes BOTH BatchNorms' backward
+// coefficients - the outer one's (sum dh, sum dh*xo) directly, the inner one's (sum dzm, sum dzm*xi with
+// dz = a_o*(dh - s0/N - xo*s1/N), dzm = m*dz) by linearity:
+//   T0 sum dh   T1 sum dh*xo   T2 sum m*dh   T3 sum m   T4 sum m*xo   T5 sum m*dh*xi   T6 sum m*xi   T7 sum m*xo*xi
+// (xi = xhat of the inner norm, m = [its pre-activation > 0], xo = xhat of the outer norm of z, z recomputed from y).
+// dz is never written: 3 launches (reduce, apply, reduce) and 100 MB per layer become 1 launch and 40 MB.
+template <int VEC, int G>
+__global__ void __launch_bounds__(kBlock) bn_bwd_reduce2_kernel(const BnParams p) {
+    const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
+    const bool col_ok = c0 < p.C;
+    double t[8][VEC];
+    for (int n = 0; n < 8; ++n) for (int q = 0; q < VEC; ++q) t[n][q] = 0.0;
+    if (col_ok) {
+        float mean[VEC], istd[VEC], g[VEC], bt[VEC], om[VEC], oi[VEC];
+        ldv<VEC>(p.mean + c0, mean); ldv<VEC>(p.invstd + c0, istd); ldv<VEC>(p.gamma + c0, g); ldv<VEC>(p.beta + c0, bt);
+        ldv<VEC>(p.o_mean + c0, om); ldv<VEC>(p.o_invstd + c0, oi);
+        const int64_t step = (int64_t)gridDim.x * (kBlock / G);
+        int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl;
+        auto one = [&](const float (&v)[VEC], const float (&dh)[VEC]) {
+            for (int q = 0; q < VEC; ++q) {
+                const float xi = (v[q] - mean[q]) * istd[q];
+                const float pre = fmaf(xi, g[q], bt[q]);
+                const bool m = !p.relu || pre > 0.f;
+                const float z = (p.relu && pre <= 0.f) ? 0.f : pre;
+                const float xo = (z - om[q]) * oi[q];
+                const double d = (double)dh[q], dxo = (double)xo;
+                t[0][q] += d;
+                t[1][q] = fma(d, dxo, t[1][q]);
+                if (m) {
+                    const double dxi = (double)xi;
+                    t[2][q] += d;
+                    t[3][q] += 1.0;
+                    t[4][q] += dxo;
+                    t[5][q] = fma(d, dxi, t[5][q]);
+                    t[6][q] += dxi;
+                    t[7][q] = fma(dxo, dxi, t[7][q]);
+                }
+            }
+        };
+        auto racc = [&](int64_t row, const float (&dh)[VEC]) {
+            float a[VEC];
+            ldv<VEC>(p.racc + row * p.racs + c0, a);
+            for (int q = 0; q < VEC; ++q) a[q] += dh[q];
+            stv<VEC>(p.racc + row * p.racs + c0, a);
+        };
+        for (; r + step < p.N; r += 2 * step) {
+            float v0[VEC], y0[VEC], v1[VEC], y1[VEC];
+            ldv<VEC>(p.x + r * p.xs + c0, v0);
+            ldv<VEC>(p.dz + r * p.dzs + c0, y0);
+            ldv<VEC>(p.x + (r + step) * p.xs + c0, v1);
+            ldv<VEC>(p.dz + (r + step) * p.dzs + c0, y1);
+            one(v0, y0);
+            one(v1, y1);
+            if (p.racc) { racc(r, y0); racc(r + step, y1); }
+        }
+        for (; r < p.N; r += step) {
+            float v[VEC], dh[VEC];
+            ldv<VEC>(p.x + r * p.xs + c0, v);
+            ldv<VEC>(p.dz + r * p.dzs + c0, dh);
+            one(v, dh);
+            if (p.racc) racc(r, dh);
+        }
+    }
+    block_to_slot_n<VEC, G, 8>(p.out_slot, p.C, t);
 }
 
 template <int VEC, int G>
@@ -319,7 +408,7 @@ extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d->reduce_only || (d->dx && d->dgamma && d->dbeta), "bn_bwd: NULL output");
     KPGNN_REQUIRE(d->stat_slot != nullptr, "bn_bwd: NULL stat_slot");
     int vec, g;
-    int rc = bn_shape(d->C, {d->x, d->dz, d->dx, d->gamma, d->beta, d->mean, d->invstd, d->dgamma, d->dbeta, d->residual_grad},
+    int rc = bn_shape(d->C, {d->x, d->dz, d->dx, d->gamma, d->beta, d->mean, d->invstd, d->dgamma, d->dbeta, d->residual_grad, d->outer_mean, d->outer_invstd},
                       {d->x_stride, d->dz_stride, d->dx ? d->dx_stride : 0, d->residual_grad ? d->rg_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
     BnParams p = {};
@@ -332,6 +421,12 @@ extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
     p.in_slot = d->stat_slot;
     hipStream_t s = (hipStream_t)stream;
     const int nstat = stream_grid(d->N, g, kProducerBlocks);
+    if (d->outer_mean) {
+        KPGNN_REQUIRE(d->reduce_only && d->outer_invstd, "bn_bwd: the stacked reduce (outer_mean) needs reduce_only and outer_invstd");
+        p.o_mean = d->outer_mean; p.o_invstd = d->outer_invstd;
+        KP_BN_SWITCH(bn_bwd_reduce2_kernel, nstat);
+        return KPGNN_OK;
+    }
     KP_BN_SWITCH(bn_bwd_reduce_kernel, nstat);
     if (d->reduce_only) return KPGNN_OK;
     const int napply = stream_grid(d->N, g, device_facts().cu_count * 8);

@@ -16,6 +16,9 @@
 //          xhat from the saved forward input x2, (s0, s1) = (sum dzm, sum dzm*xhat) from `in_slot`; dy is also
 //          written out (the weight-gradient kernel reads it); block 0 publishes dbeta = s0, dgamma = s1
 //   EPI 0  y is stored as is
+//   PRO 3  two stacked BatchNorms' backward on load (y -> z = relu(bn_in(y)) -> h = bn_out(z)): x is dh, x2 is y, in_slot
+//          holds the eight sums of bn.hip's stacked reduce; dz = a_o*(dh - s0o/N - xo*s1o/N) is formed in registers (z and
+//          xo recomputed from y), then PRO 2's arithmetic on it.  Writes dgamma / dbeta of both norms.
 //   EPI 1  + column sums (sum y, sum y^2) of the result into `out_slot`            (statistics of the next BatchNorm)
 //   EPI 2  y is masked by the ReLU of the PREVIOUS BatchNorm (recomputed from its saved input e_x) and the column
 //          sums (sum ym, sum ym * xhat_e) go to `out_slot`                        (backward reduce of that BatchNorm)
@@ -47,6 +50,8 @@ struct LinFParams {
     const float* x2;                             // PRO 2: forward input of the BatchNorm ([N,I], contiguous)
     float* xt;                                   // PRO 2: transformed tile written out ([N,I]) or NULL
     float* dgamma; float* dbeta;                 // PRO 2: outputs (block 0)
+    const float* o_mean; const float* o_invstd; const float* o_gamma;   // PRO 3: the outer BatchNorm
+    float* o_dgamma; float* o_dbeta;             // PRO 3: outputs (block 0)
     // EPI 1 / 2
     double* out_slot;
     const float* e_x; const float* e_mean; const float* e_invstd; const float* e_gamma; const float* e_beta;   // EPI 2
@@ -72,8 +77,8 @@ lin_fused_kernel(const LinFParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 5, c = lane & 31;
     const int O = p.O, pitch = p.pitch;
-    float* cin = xl + ROWS * pitch;                   // PRO coefficients: [7][I]
-    float* cout = cin + 7 * I;                        // EPI 2 coefficients: [4][O]
+    float* cin = xl + ROWS * pitch;                   // PRO coefficients: [12][I] (rows 7..11: PRO 3's outer norm)
+    float* cout = cin + 12 * I;                       // EPI 2 coefficients: [4][O]
     const int o = wave * 32 + c;
     // this wave's strip of the weight as MFMA A-fragments: a[ks] = W[o][2 ks + kk]
     float a[KS];
@@ -116,6 +121,31 @@ lin_fused_kernel(const LinFParams p) {
         cin[4 * I + tid] = ai; cin[5 * I + tid] = ai * (float)(s0 * inv_n); cin[6 * I + tid] = ai * (float)(s1 * inv_n);
         if (blockIdx.x == 0) { p.dbeta[tid] = (float)s0; p.dgamma[tid] = (float)s1; }
     }
+    if (PRO == 3 && tid < I) {
+        const double inv_n = 1.0 / (double)p.N;
+        double t[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < KPGNN_STAT_REPLICAS; ++r) a += p.in_slot[((int64_t)r * 8 + n) * I + tid];
+            t[n] = a;
+        }
+        const float mean = p.in_mean[tid], istd = p.in_invstd[tid], g = p.in_gamma[tid];
+        const float om = p.o_mean[tid], oi = p.o_invstd[tid];
+        const float ai = g * istd, ao = p.o_gamma[tid] * oi;
+        const double m0 = t[0] * inv_n, m1 = t[1] * inv_n;                  // outer: s0/N, s1/N
+        const double s0 = (double)ao * (t[2] - m0 * t[3] - m1 * t[4]);        // inner: sum dzm
+        const double s1 = (double)ao * (t[5] - m0 * t[6] - m1 * t[7]);        //        sum dzm * xhat_in
+        cin[tid] = mean; cin[I + tid] = istd; cin[2 * I + tid] = g; cin[3 * I + tid] = p.in_beta[tid];
+        cin[4 * I + tid] = ai; cin[5 * I + tid] = ai * (float)(s0 * inv_n); cin[6 * I + tid] = ai * (float)(s1 * inv_n);
+        cin[7 * I + tid] = om; cin[8 * I + tid] = oi; cin[9 * I + tid] = ao;
+        cin[10 * I + tid] = ao * (float)m0; cin[11 * I + tid] = ao * (float)m1;
+        if (blockIdx.x == 0) {
+            p.dbeta[tid] = (float)s0; p.dgamma[tid] = (float)s1;
+            p.o_dbeta[tid] = (float)t[0]; p.o_dgamma[tid] = (float)t[1];
+        }
+    }
     if (EPI == 2 && tid < O) {
         cout[tid] = p.e_mean[tid]; cout[O + tid] = p.e_invstd[tid]; cout[2 * O + tid] = p.e_gamma[tid]; cout[3 * O + tid] = p.e_beta[tid];
     }
@@ -157,6 +187,9 @@ lin_fused_kernel(const LinFParams p) {
         const float4 mean = ld4(cin + 4 * cgi), istd = ld4(cin + I + 4 * cgi), g = ld4(cin + 2 * I + 4 * cgi),
                      bt = ld4(cin + 3 * I + 4 * cgi), ai = ld4(cin + 4 * I + 4 * cgi), k0 = ld4(cin + 5 * I + 4 * cgi),
                      k1 = ld4(cin + 6 * I + 4 * cgi);
+        float4 om, oi, ao, q0, q1;
+        if (PRO == 3) { om = ld4(cin + 7 * I + 4 * cgi); oi = ld4(cin + 8 * I + 4 * cgi); ao = ld4(cin + 9 * I + 4 * cgi);
+                        q0 = ld4(cin + 10 * I + 4 * cgi); q1 = ld4(cin + 11 * I + 4 * cgi); }
         float4 dz[PFI], xs[PFI];
 #pragma unroll
         for (int j = 0; j < PFI; ++j) {
@@ -172,7 +205,11 @@ lin_fused_kernel(const LinFParams p) {
                 float4 v;
                 const bool in = r0 + rli + j * RLI < p.N;
 #define KP_BWD1(f) { const float xh = (xs[j].f - mean.f) * istd.f; float d = dz[j].f; \
-                     if (p.pro_relu && fmaf(xh, g.f, bt.f) <= 0.f) d = 0.f; \
+                     const float pre = fmaf(xh, g.f, bt.f); \
+                     if (PRO == 3) { const float zz = (p.pro_relu && pre <= 0.f) ? 0.f : pre; \
+                                     const float xo = (zz - om.f) * oi.f; \
+                                     d = fmaf(-xo, q1.f, fmaf(ao.f, d, -q0.f)); } \
+                     if (p.pro_relu && pre <= 0.f) d = 0.f; \
                      v.f = in ? fmaf(-xh, k1.f, fmaf(ai.f, d, -k0.f)) : 0.f; }
                 KP_BWD1(x) KP_BWD1(y) KP_BWD1(z) KP_BWD1(w)
 #undef KP_BWD1
@@ -188,12 +225,12 @@ lin_fused_kernel(const LinFParams p) {
     double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};   // EPI 1 / 2 column partials of this thread
 
     int64_t tile = blockIdx.x;
-    if (PRO != 2) { if (tile < tiles) { issue(tile); commit(); } }
+    if (PRO < 2) { if (tile < tiles) { issue(tile); commit(); } }
     else if (tile < tiles) load_bwd(tile);
     __syncthreads();
     for (; tile < tiles; tile += gridDim.x) {
         const bool more = tile + gridDim.x < tiles;
-        if (PRO != 2 && more) issue(tile + gridDim.x);
+        if (PRO < 2 && more) issue(tile + gridDim.x);
         f32x16 acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m)
@@ -248,7 +285,7 @@ lin_fused_kernel(const LinFParams p) {
                 }
         }
         __syncthreads();                               // the y tile is out: the buffer takes the next x tile
-        if (more) { if (PRO != 2) commit(); else load_bwd(tile + gridDim.x); }
+        if (more) { if (PRO < 2) commit(); else load_bwd(tile + gridDim.x); }
         __syncthreads();
     }
     if (EPI != 0) {
@@ -280,8 +317,8 @@ inline LinLaunch lin_plan(int64_t N, int O, int I) {
     int m = (int)((N + slots * 32 - 1) / (slots * 32));
     L.m = m < 1 ? 1 : (m > 3 ? 3 : m);
     const int rows = 32 * L.m;
-    // tile + 7 input-side + 4 output-side coefficient rows; the fp64 block reduction of the statistics reuses the tile
-    size_t fl = (size_t)rows * L.pitch + 7 * (size_t)I + 4 * (size_t)O;
+    // tile + 12 input-side + 4 output-side coefficient rows; the fp64 block reduction of the statistics reuses the tile
+    size_t fl = (size_t)rows * L.pitch + 12 * (size_t)I + 4 * (size_t)O;
     const size_t red = 2 * (size_t)(256 / (O / 4)) * 2 * O;      // doubles, counted in floats
     if (fl < red) fl = red;
     L.lds = sizeof(float) * fl;
@@ -324,5 +361,6 @@ int lin_launch_bn_stats(const LinFParams& p, hipStream_t s);    // PRO 1, EPI 1
 int lin_launch_bn(const LinFParams& p, hipStream_t s);          // PRO 1, EPI 0
 int lin_launch_bwd_reduce(const LinFParams& p, hipStream_t s);  // PRO 2, EPI 2
 int lin_launch_bwd(const LinFParams& p, hipStream_t s);         // PRO 2, EPI 0
+int lin_launch_bwd2_reduce(const LinFParams& p, hipStream_t s); // PRO 3, EPI 2
 
 }  // namespace kpgnn

@@ -7,7 +7,7 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
     KPGNN_REQUIRE(d != nullptr, "linear_bn: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_bn: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
     KPGNN_REQUIRE(d->x && d->w && d->y, "linear_bn: NULL pointer");
-    KPGNN_REQUIRE(d->pro >= 0 && d->pro <= 2 && d->epi >= 0 && d->epi <= 2, "linear_bn: bad pro=%d / epi=%d", d->pro, d->epi);
+    KPGNN_REQUIRE(d->pro >= 0 && d->pro <= 3 && d->epi >= 0 && d->epi <= 2, "linear_bn: bad pro=%d / epi=%d", d->pro, d->epi);
     if (!lin_supported_width(d->I) || (d->O % 4) != 0 || d->O > 128)
         return fail(KPGNN_ELIMIT, "linear_bn: I=%d must be one of 32, 64, 96, 104, 128 and O=%d a multiple of 4 <= 128", d->I, d->O);
     uintptr_t al = (uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->bias | (uintptr_t)d->x2 | (uintptr_t)d->xt | (uintptr_t)d->e_x;
@@ -22,9 +22,14 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
         p.in_eps = d->in_eps; p.momentum = d->momentum; p.in_mean = d->in_mean; p.in_invstd = d->in_invstd;
         p.rmean = d->running_mean; p.rvar = d->running_var; p.nbt = d->num_batches_tracked;
     }
-    if (d->pro == 2) {
-        KPGNN_REQUIRE(d->x2 && d->dgamma && d->dbeta, "linear_bn: pro 2 needs x2, dgamma, dbeta");
+    if (d->pro >= 2) {
+        KPGNN_REQUIRE(d->x2 && d->dgamma && d->dbeta, "linear_bn: pro %d needs x2, dgamma, dbeta", d->pro);
         p.x2 = d->x2; p.xt = d->xt; p.dgamma = d->dgamma; p.dbeta = d->dbeta;
+    }
+    if (d->pro == 3) {
+        KPGNN_REQUIRE(d->o_mean && d->o_invstd && d->o_gamma && d->o_dgamma && d->o_dbeta,
+                      "linear_bn: pro 3 needs o_mean, o_invstd, o_gamma, o_dgamma, o_dbeta");
+        p.o_mean = d->o_mean; p.o_invstd = d->o_invstd; p.o_gamma = d->o_gamma; p.o_dgamma = d->o_dgamma; p.o_dbeta = d->o_dbeta;
     }
     if (d->epi != 0) {
         KPGNN_REQUIRE(d->out_slot != nullptr, "linear_bn: epi %d needs out_slot", d->epi);
@@ -42,6 +47,7 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
         case 11: return lin_launch_bn_stats(p, s);
         case 20: return lin_launch_bwd(p, s);
         case 22: return lin_launch_bwd_reduce(p, s);
+        case 32: return lin_launch_bwd2_reduce(p, s);
         default: return fail(KPGNN_ELIMIT, "linear_bn: combination pro=%d epi=%d is not instantiated", d->pro, d->epi);
     }
 }

@@ -36,16 +36,19 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
         if self.K > 1:
             self.combine.reset_parameters()
 
-    def forward_slots(self, h_slots, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, history=False):
+    def forward_slots(self, h_slots, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, history=False, post_norm=None):
         """Same as forward(torch.stack(h_slots, 1), ...) without the stacking copy (and without the slicing
         adds in backward): hop slot m reads h_slots[m] ([N,H]) where it lives.  Extension of the reference API
-        used by kp_gnn_amd.body.GNNPlus; GNNs.py:413-418 builds the stack with torch.cat every layer."""
+        used by kp_gnn_amd.body.GNNPlus; GNNs.py:413-418 builds the stack with torch.cat every layer.
+        post_norm = (nn.BatchNorm1d, residual or None): return bn(result) + residual instead (the body's per-layer norm,
+        GNNs.py:440-441, taken into the layer's last autograd node: ops_dense.FusedMLP)."""
         from ..khop_csr import path_encoding_is_zero
         if self.K > 1 and pe_attr is not None and not path_encoding_is_zero(pe_attr):
-            return self.forward(torch.stack(list(h_slots), dim=1), edge_index, edge_attr, pe_attr, peripheral_attr)
-        return self.forward(list(h_slots), edge_index, edge_attr, pe_attr, peripheral_attr, _history=history)
+            return self.forward(torch.stack(list(h_slots), dim=1), edge_index, edge_attr, pe_attr, peripheral_attr,
+                                _post_norm=post_norm)
+        return self.forward(list(h_slots), edge_index, edge_attr, pe_attr, peripheral_attr, _history=history, _post_norm=post_norm)
 
-    def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, _history=False):
+    def forward(self, x, edge_index, edge_attr, pe_attr=None, peripheral_attr=None, _history=False, _post_norm=None):
         n = x[0].size(0) if isinstance(x, list) else x.size(0)
         csr, k_act = self._csr(edge_index, edge_attr, n)
         x, xbias = self._path_encoding(x, pe_attr)
@@ -58,4 +61,4 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
                                 xbias=xbias, share_slot_grads=_history)                       # N,k,H
             h = self.combine(xn)
         # (_kp_emit_out_stats: set by a caller that applies a BatchNorm to the result next - kp_gnn_amd.body does)
-        return mlp_linear_bn_relu_x2(self.mlp, h, emit_out_stats=getattr(self, "_kp_emit_out_stats", False))
+        return mlp_linear_bn_relu_x2(self.mlp, h, emit_out_stats=getattr(self, "_kp_emit_out_stats", False), post_norm=_post_norm)

@@ -250,21 +250,29 @@ class FusedMLP(torch.autograd.Function):
            of y2) | z = relu(bn2(y2)) (+ sums of z for the caller's next BatchNorm, when asked)
       bwd  bn2 reduce | dy2 = bn2'(dz) on load, da1 = dy2 W3 masked by relu1, bn1 reduce in the epilogue | dy1 = bn1'(da1)
            on load, dh = dy1 W0 | both weight gradients in one launch (relu(bn1(y1)) recomputed on load) + one reduce.
-    The activations a1 = relu(bn1(y1)) are never written to memory."""
+    The activations a1 = relu(bn1(y1)) are never written to memory.
+
+    With an OUTER BatchNorm (gO, beO, bnO: the bodies' per-layer norm, models/GNNs.py:440-441, + optional residual) the
+    node returns bnO(z) + residual: one more apply launch forward, and backward STILL 5 launches - the outer norm's reduce,
+    its apply and bn2's reduce (three passes, dz written and read back) become one stacked reduce over (dh, y2), and both
+    norms' backward arithmetic happens while the first GEMM loads its tile (kpgnn_linear_bn pro 3)."""
 
     @staticmethod
-    def forward(ctx, h, w0, b0, g1, be1, w3, b3, g2, be2, bn1, bn2, out_slot):
+    def forward(ctx, h, w0, b0, g1, be1, w3, b3, g2, be2, bn1, bn2, out_slot, gO=None, beO=None, residual=None, bnO=None):
         lib = _lib.load()
         dev = h.device
         N, I = h.shape
         O = w0.shape[0]
         h = h.contiguous()
         w0c, w3c = w0.contiguous(), w3.contiguous()
+        outer = bnO is not None
         slot1, slot2 = take_stat_slot(O, dev), take_stat_slot(O, dev)
+        if outer:
+            out_slot = take_stat_slot(O, dev)
         y1 = torch.empty((N, O), dtype=torch.float32, device=dev)
         y2 = torch.empty((N, O), dtype=torch.float32, device=dev)
         z = torch.empty((N, O), dtype=torch.float32, device=dev)
-        st = torch.empty((4, O), dtype=torch.float32, device=dev)      # mean1, invstd1, mean2, invstd2
+        st = torch.empty((6, O), dtype=torch.float32, device=dev)      # mean1, invstd1, mean2, invstd2, meanO, invstdO
         _lin_bn(lib, dev, N=N, O=O, I=I, x=h, w=w0c, bias=b0, y=y1, pro=0, epi=1, out_slot=slot1)
         track1 = bn1.track_running_stats
         _lin_bn(lib, dev, N=N, O=O, I=O, x=y1, w=w3c, bias=b3, y=y2, pro=1, epi=1, pro_relu=1, in_slot=slot1, in_gamma=g1,
@@ -281,34 +289,66 @@ class FusedMLP(torch.autograd.Function):
         d.stat_slot, d.stats_ready, d.out_slot = slot2.data_ptr(), 1, _ptr(out_slot)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_fwd")
-        ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st)
+        out = z
+        ctx.outer, ctx.has_res, ctx.res_cell = outer, False, None
+        if outer:
+            out = torch.empty((N, O), dtype=torch.float32, device=dev)
+            e = _lib.BnDesc()
+            e.N, e.C, e.relu, e.eps, e.momentum = N, O, 0, float(bnO.eps), float(bnO.momentum)
+            e.x, e.x_stride, e.gamma, e.beta = z.data_ptr(), O, gO.data_ptr(), beO.data_ptr()
+            if bnO.track_running_stats:
+                e.running_mean, e.running_var = bnO.running_mean.data_ptr(), bnO.running_var.data_ptr()
+                e.num_batches_tracked = bnO.num_batches_tracked.data_ptr()
+            e.mean, e.invstd, e.z, e.z_stride = st[4].data_ptr(), st[5].data_ptr(), out.data_ptr(), O
+            if residual is not None:
+                residual = residual if residual.stride(-1) == 1 else residual.contiguous()
+                e.residual, e.r_stride = residual.data_ptr(), residual.stride(0)
+                ctx.has_res = True
+                ctx.res_cell = getattr(residual, "_kp_slot_cell", None)
+            e.stat_slot, e.stats_ready = out_slot.data_ptr(), 1
+            with torch.cuda.device(dev):
+                _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(e), _stream(h)), "kpgnn_bn_fwd")
+            ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st, gO)
+        else:
+            ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st)
         ctx.has_b0, ctx.has_b3 = b0 is not None, b3 is not None
-        return z
+        return out
 
     @staticmethod
     def backward(ctx, dz):
-        h, w0, w3, g1, be1, g2, be2, y1, y2, st = ctx.saved_tensors
+        if ctx.outer:
+            h, w0, w3, g1, be1, g2, be2, y1, y2, st, gO = ctx.saved_tensors
+        else:
+            h, w0, w3, g1, be1, g2, be2, y1, y2, st = ctx.saved_tensors
         lib = _lib.load()
         dev = h.device
         N, I = h.shape
         O = w0.shape[0]
         dz = dz.contiguous()
-        slot2, slot1 = take_stat_slot(O, dev), take_stat_slot(O, dev)
+        slot2, slot1 = take_stat_slot(4 * O if ctx.outer else O, dev), take_stat_slot(O, dev)
         dy2 = torch.empty((N, O), dtype=torch.float32, device=dev)
         da1 = torch.empty((N, O), dtype=torch.float32, device=dev)
         dy1 = torch.empty((N, O), dtype=torch.float32, device=dev)
         dh = torch.empty((N, I), dtype=torch.float32, device=dev)
-        gb = torch.empty((4, O), dtype=torch.float32, device=dev)      # dgamma2, dbeta2, dgamma1, dbeta1
+        gb = torch.empty((6, O), dtype=torch.float32, device=dev)      # dgamma2, dbeta2, dgamma1, dbeta1, dgammaO, dbetaO
         d = _lib.BnBwdDesc()
         d.N, d.C, d.relu = N, O, 1
         d.x, d.x_stride, d.dz, d.dz_stride = y2.data_ptr(), O, dz.data_ptr(), O
         d.gamma, d.beta, d.mean, d.invstd = g2.data_ptr(), be2.data_ptr(), st[2].data_ptr(), st[3].data_ptr()
         d.stat_slot, d.reduce_only = slot2.data_ptr(), 1
+        rbuf = None
+        if ctx.outer:
+            # the residual branch: a state whose gradient is collected in a cell gets += dz from the reduce pass itself
+            rbuf = ctx.res_cell.buf if (ctx.res_cell is not None and ctx.needs_input_grad[14]) else None
+            d.outer_mean, d.outer_invstd = st[4].data_ptr(), st[5].data_ptr()
+            if rbuf is not None:
+                d.residual_grad, d.rg_stride = rbuf.data_ptr(), rbuf.stride(0)
         with torch.cuda.device(dev):
             _lib.check(lib.kpgnn_bn_bwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_bwd")
-        _lin_bn(lib, dev, N=N, O=O, I=O, x=dz, w=w3, y=da1, w_transposed=1, pro=2, epi=2, pro_relu=1, in_slot=slot2,
+        okw = dict(pro=3, o_mean=st[4], o_invstd=st[5], o_gamma=gO, o_dgamma=gb[4], o_dbeta=gb[5]) if ctx.outer else dict(pro=2)
+        _lin_bn(lib, dev, N=N, O=O, I=O, x=dz, w=w3, y=da1, w_transposed=1, epi=2, pro_relu=1, in_slot=slot2,
                 in_gamma=g2, in_beta=be2, in_mean=st[2], in_invstd=st[3], x2=y2, xt=dy2, dgamma=gb[0], dbeta=gb[1],
-                out_slot=slot1, e_x=y1, e_mean=st[0], e_invstd=st[1], e_gamma=g1, e_beta=be1)
+                out_slot=slot1, e_x=y1, e_mean=st[0], e_invstd=st[1], e_gamma=g1, e_beta=be1, **okw)
         _lin_bn(lib, dev, N=N, O=I, I=O, x=da1, w=w0, y=dh, w_transposed=1, pro=2, epi=0, pro_relu=0, in_slot=slot1,
                 in_gamma=g1, in_beta=be1, in_mean=st[0], in_invstd=st[1], x2=y1, xt=dy1, dgamma=gb[2], dbeta=gb[3])
         # weight gradients: dW3 = dy2^T relu(bn1(y1)), dW0 = dy1^T h
@@ -335,33 +375,44 @@ class FusedMLP(torch.autograd.Function):
                     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                     q.workspace, q.workspace_bytes = ws.data_ptr(), nb
                     _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(q), _stream(h)), "kpgnn_linear_wgrad")
+        gres = dz if (ctx.outer and ctx.has_res and rbuf is None) else None
         return (dh if ctx.needs_input_grad[0] else None, dw0, db[1] if ctx.has_b0 else None, gb[2], gb[3],
-                dw3, db[0] if ctx.has_b3 else None, gb[0], gb[1], None, None, None)
+                dw3, db[0] if ctx.has_b3 else None, gb[0], gb[1], None, None, None,
+                gb[4] if ctx.outer else None, gb[5] if ctx.outer else None, gres, None)
 
 
 def _fusable_bn(bn):
     return bn.training and bn.affine and bn.momentum is not None
 
 
-def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False):
+def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False, post_norm=None):
     """nn.Sequential(Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU) (KPGINplus.py:25-30, gine.py:31-38).
     Training mode on covered widths: the fused 3 + 5 launch path (FusedMLP); otherwise Linear and BatchNorm one by one.
     emit_out_stats: also accumulate the column statistics of the result and attach them to it, for a BatchNorm the
-    caller applies next (the bodies' per-layer norm)."""
+    caller applies next (the bodies' per-layer norm).
+    post_norm = (nn.BatchNorm1d, residual or None): the caller's next step IS bn(result) + residual - returned instead of
+    the MLP's output, by the same autograd node when fused (FusedMLP: the backward saves two passes)."""
     l0, bn1, l3, bn2 = mlp[0], mlp[1], mlp[3], mlp[4]
     O, I = l0.weight.shape
+    bnO, res = post_norm if post_norm is not None else (None, None)
     if (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and torch.is_grad_enabled() and _fusable_bn(bn1)
             and _fusable_bn(bn2) and I in _LIN_WIDTHS and O in _LIN_WIDTHS and tuple(l3.weight.shape) == (O, O)
             and h.shape[0] >= 1 and h.data_ptr() % 16 == 0
             and (l0.bias is None or l0.bias.data_ptr() % 16 == 0) and (l3.bias is None or l3.bias.data_ptr() % 16 == 0)):
-        out_slot = take_stat_slot(O, h.device) if emit_out_stats else None
+        if (bnO is not None and _fusable_bn(bnO) and bnO.weight.data_ptr() % 16 == 0 and bnO.bias.data_ptr() % 16 == 0
+                and (res is None or (res.is_cuda and res.dtype == torch.float32 and tuple(res.shape) == (h.shape[0], O)
+                                     and res.stride(0) % 4 == 0 and res.data_ptr() % 16 == 0))):
+            return FusedMLP.apply(h, l0.weight, l0.bias, bn1.weight, bn1.bias, l3.weight, l3.bias, bn2.weight, bn2.bias,
+                                  bn1, bn2, None, bnO.weight, bnO.bias, res, bnO)
+        out_slot = take_stat_slot(O, h.device) if (emit_out_stats or bnO is not None) else None
         z = FusedMLP.apply(h, l0.weight, l0.bias, bn1.weight, bn1.bias, l3.weight, l3.bias, bn2.weight, bn2.bias, bn1, bn2,
                            out_slot)
         if out_slot is not None:
             attach_column_stats(z, out_slot)
-        return z
-    h = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
-    return batch_norm_act(linear(h, mlp[3]), mlp[4], relu=True)
+    else:
+        z = batch_norm_act(linear(h, mlp[0]), mlp[1], relu=True)
+        z = batch_norm_act(linear(z, mlp[3]), mlp[4], relu=True)
+    return z if bnO is None else batch_norm_act(z, bnO, relu=False, residual=res)
 
 
 # ------------------------------------------------------------------------------------ jumping-knowledge projection

@@ -1172,7 +1172,7 @@ def test_embedding_rows_validates_range_and_padding():
 def _gpu_relu_masks(node):
     """The ReLU masks the GPU forward used, rebuilt bit-exactly from what FusedMLP saved: pre = fmaf((y - mean) * invstd,
     gamma, beta) > 0 (the sign of an fmaf is the sign of the exact a*b + c, which float64 holds exactly)."""
-    h, w0, w3, g1, be1, g2, be2, y1, y2, st = [t.detach().cpu() for t in node.saved_tensors]
+    h, w0, w3, g1, be1, g2, be2, y1, y2, st = [t.detach().cpu() for t in node.saved_tensors[:10]]
     def mask(y, mean, istd, g, b):
         xh = (y - mean) * istd                                   # two fp32 roundings, as on the device
         return (xh.double() * g.double() + b.double()) > 0
@@ -1181,12 +1181,14 @@ def _gpu_relu_masks(node):
 
 @pytest.mark.parametrize("N,I,O", [(4099, 104, 104), (1500, 64, 104), (47450, 104, 104), (33, 32, 32), (2048, 96, 96),
                                    (2500, 128, 128), (1000, 104, 64), (32768, 104, 104), (17, 32, 32)])
-@pytest.mark.parametrize("follow_norm", [False, True])
+@pytest.mark.parametrize("follow_norm", [False, True, "fused", "fused_cell"])
 def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     """kpgnn_linear_bn + slots: Linear-BN-ReLU-Linear-BN-ReLU (KPGINplus.py:25-30) in 3 + 5 launches against the same
     sequence of torch ops on the CPU (training mode): output, running statistics, the input gradient and every parameter
     gradient; follow_norm adds the bodies' next BatchNorm + residual, which takes its statistics from the slot the MLP's
-    last kernel filled (no stats pass).  Large means exercise the fp64 statistics.
+    last kernel filled (no stats pass); "fused" hands that norm to the MLP's own autograd node (post_norm: the backward's
+    stacked reduce + kpgnn_linear_bn pro 3), "fused_cell" with the residual's gradient collected in a state cell.
+    Large means exercise the fp64 statistics.
     With millions of elements a few pre-activations land within rounding of the ReLU kink, where the reference's and
     our mean / invstd (different summation order) decide the sign differently and a whole row of the backward differs
     legitimately: the CPU side therefore applies the ReLUs as multiplications by the masks the GPU forward used (rebuilt
@@ -1209,11 +1211,17 @@ def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     res = torch.randn(N, O, generator=g)
     w = torch.randn(N, O, generator=g)
     xd, rd = x.to(dev).requires_grad_(True), res.to(dev).requires_grad_(True)
-    outd = mlp_linear_bn_relu_x2(hip, xd, emit_out_stats=follow_norm)
+    cell = None
+    if follow_norm == "fused_cell":
+        from kp_gnn_amd import ops
+        cell = ops.state_cell(rd)
+        cell.buf = torch.full((N, O), 0.25, device=dev)          # (a later reader's share, already parked)
+    post = (norm_hip, rd) if follow_norm in ("fused", "fused_cell") else None
+    outd = mlp_linear_bn_relu_x2(hip, xd, emit_out_stats=bool(follow_norm), post_norm=post)
     node = outd.grad_fn
     assert isinstance(node, FusedMLP._backward_cls)              # the fused path ran
     m1, m2 = _gpu_relu_masks(node)
-    if follow_norm:
+    if follow_norm is True:
         from kp_gnn_amd import ops_dense
         assert ops_dense._column_stats_of(outd) is not None      # ... and left its statistics for the next BatchNorm
         outd = batch_norm_act(outd, norm_hip, relu=False, residual=rd)
@@ -1229,7 +1237,10 @@ def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     (out * w).sum().backward()
     _close(outd, out, "out", rtol=2e-4, atol=3e-5)
     _close(xd.grad, xr.grad, "dx", rtol=3e-4, atol=5e-5)
-    if follow_norm:
+    if cell is not None:
+        assert rd.grad is None
+        _close(cell.buf - 0.25, rr.grad, "dres (cell)")
+    elif follow_norm:
         _close(rd.grad, rr.grad, "dres")
     pr, ph = dict(ref.named_parameters()), dict(hip.named_parameters())
     if follow_norm:
@@ -1356,3 +1367,35 @@ def test_enc_tables_vs_framework_ops(H, kind):
     _close(res[1][1], res[0][1], "bias", rtol=2e-4, atol=2e-5)
     for i, (a, b) in enumerate(zip(res[1][2], res[0][2])):
         _close(a, b, f"grad[{i}]", rtol=3e-4, atol=3e-5)
+
+
+def test_copy_grads_is_exact_and_replays_in_a_graph():
+    """dp.copy_grads (kpgnn_multi_copy): 200 ragged tensors - more than one launch's pointer table, unaligned views, an
+    empty one - land bit-for-bit in their views of a flat bucket, eagerly and when replayed from a captured graph."""
+    from kp_gnn_amd import dp
+    DEV = _dev()
+    g = torch.Generator().manual_seed(5)
+    sizes = [int(s) for s in torch.randint(1, 3000, (199,), generator=g)] + [0, 104 * 832]
+    grads = [torch.randn(s, generator=g).to(DEV) for s in sizes]
+    flat = torch.zeros(sum(sizes) + 3, device=DEV)
+    views, off = [], 3                      # offset 3: most views are not 16-byte aligned
+    for s in sizes:
+        views.append(flat[off:off + s]); off += s
+    dp.copy_grads(views, grads)
+    want = torch.cat([torch.zeros(3, device=DEV)] + grads)
+    assert torch.equal(flat, want)
+    flat.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dp.copy_grads(views, grads)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dp.copy_grads(views, grads)
+    for t in grads:
+        t.mul_(2.0)
+    flat.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(flat, torch.cat([torch.zeros(3, device=DEV)] + grads))      # the doubled sources
