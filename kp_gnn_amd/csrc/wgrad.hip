@@ -4,8 +4,11 @@
 // v_mfma_f32_32x32x2_f32 (exact f32, fmaf-chain numerics): lane l feeds A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]; with A = dy^T and B = x and k = two consecutive rows r0, r0+1 both operands are plain
 // coalesced reads of 32 consecutive floats of a row - straight from global memory, no LDS, no transposes.
-// Wave w of a block owns output rows o in [32w, 32w+32) and ALL column tiles (TI accumulators of 16 VGPRs);
-// blocks split the N rows; partial dW strips go to a slab that is added in block order.
+// A wave owns a strip of output rows o in [32s, 32s+32) and ALL column tiles (TI accumulators of 16 VGPRs); the N rows
+// are split over blocks and - for O <= 128 - over the RG = 2 row groups of a block, whose partial strips meet in LDS
+// (fixed order) before ONE partial per block goes to a slab that is added in block order.  The slab is what a launch
+// leaves behind: 512 single-group blocks wrote (and the reduce launch re-read) 44.7 MB per pair of 104 x 104 problems,
+// against 80 MB of operands; two groups per block halve it.
 #include <cstdlib>
 
 #include "kpgnn_common.h"
@@ -29,11 +32,14 @@ struct WgPair { WgParams q[2]; };
 // One problem, worked through by the whole grid.  `p` is passed BY VALUE from a compile-time index of the kernel argument,
 // so its fields live in scalar registers (indexing the argument array with a runtime problem index made every use a
 // scalar load from the kernel-argument segment inside the row loop: 46 instead of 28 us per problem).
-template <int TI>
-__device__ __forceinline__ void wgrad_problem(const WgParams p) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+template <int TI, int RG>
+__device__ __forceinline__ void wgrad_problem(const WgParams p, float* lds) {
+    const int lane = threadIdx.x & 63;
+    const int nstrip = (int)(blockDim.x >> 6) / RG;
+    const int wave = (int)(threadIdx.x >> 6) % nstrip, rg = (int)(threadIdx.x >> 6) / nstrip;   // strip, row group
     const int kk = lane >> 5, c = lane & 31;
     const int o = wave * 32 + c;                 // this lane's dy column
+    const int64_t vgrid = (int64_t)gridDim.x * RG, vb = (int64_t)blockIdx.x * RG + rg;          // row-group granularity
     const bool o_ok = o < p.O;
     f32x16 acc[TI];
 #pragma unroll
@@ -53,11 +59,11 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p) {
     // rows of this block: pairs (r, r+1); block b takes pairs b, b+grid, ...
     const int64_t pairs = (p.N + 1) / 2;
     constexpr int UN = 4;
-    for (int64_t pr = blockIdx.x; pr < pairs; pr += (int64_t)gridDim.x * UN) {
+    for (int64_t pr = vb; pr < pairs; pr += vgrid * UN) {
         float a[UN], b[UN][TI];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int64_t r = 2 * (pr + (int64_t)u * gridDim.x) + kk;
+            const int64_t r = 2 * (pr + (int64_t)u * vgrid) + kk;
             const bool r_ok = r < p.N;
             a[u] = (r_ok && o_ok) ? p.dy[r * p.dys + o] : 0.f;
 #pragma unroll
@@ -69,7 +75,7 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p) {
         if (tr) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const bool r_ok = 2 * (pr + (int64_t)u * gridDim.x) + kk < p.N;
+                const bool r_ok = 2 * (pr + (int64_t)u * vgrid) + kk < p.N;
 #pragma unroll
                 for (int t = 0; t < TI; ++t) {
                     float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
@@ -85,8 +91,27 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p) {
             for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
         }
     }
+    bsum += __shfl_xor(bsum, 32);                // the two k halves hold different rows of the same column
+    if (RG > 1) {                                // group 1's partial strip joins group 0's: registers -> LDS -> registers
+        float* sl = lds + (size_t)wave * (TI * 16 + 1) * 64 + lane;
+        __syncthreads();                         // (a previous problem's readers are done with the buffer)
+        if (rg == 1) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+                for (int v = 0; v < 16; ++v) sl[(t * 16 + v) * 64] = acc[t][v];
+            sl[TI * 16 * 64] = bsum;
+        }
+        __syncthreads();
+        if (rg == 0) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+                for (int v = 0; v < 16; ++v) acc[t][v] += sl[(t * 16 + v) * 64];
+            bsum += sl[TI * 16 * 64];
+        }
+    }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* out = p.slab + (int64_t)blockIdx.x * p.slab_row + p.slab_off;
+    if (rg == 0) {
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
         const int i = t * 32 + c;
@@ -95,22 +120,23 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p) {
             if (orow < p.O && i < p.I) out[(int64_t)orow * p.I + i] = acc[t][v];
         }
     }
-    bsum += __shfl_xor(bsum, 32);                // the two k halves hold different rows of the same column
     if (kk == 0 && o_ok) out[(int64_t)p.O * p.I + o] = bsum;
+    }
 }
 
 // Two problems of one launch are worked through one after the other by the SAME grid: each keeps the single launch's
 // access pattern and block count (side by side on half the blocks each they measured 94 us against 2 x 28 us).
-template <int TI>
+template <int TI, int RG>
 __global__ void __launch_bounds__(512)
 wgrad_kernel(const WgPair pp, int nprob) {
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];     // RG 2: [strips][TI * 16 + 1][64]
     if (gridDim.y > 1) {       // small batches: the two problems side by side (a block's serial chain is what a launch costs there)
-        if (blockIdx.y == 0) wgrad_problem<TI>(pp.q[0]);
-        else wgrad_problem<TI>(pp.q[1]);
+        if (blockIdx.y == 0) wgrad_problem<TI, RG>(pp.q[0], wg_lds);
+        else wgrad_problem<TI, RG>(pp.q[1], wg_lds);
         return;
     }
-    wgrad_problem<TI>(pp.q[0]);
-    if (nprob > 1) wgrad_problem<TI>(pp.q[1]);
+    wgrad_problem<TI, RG>(pp.q[0], wg_lds);
+    if (nprob > 1) wgrad_problem<TI, RG>(pp.q[1], wg_lds);
 }
 
 // Blocks of a launch: every block writes a full O x I partial to the slab, so a small batch must not spread its few rows
@@ -139,21 +165,35 @@ WgParams wgrad_params(const kpgnn_wgrad_desc* d, float* slab, int64_t slab_row, 
     return p;
 }
 
+int wgrad_groups(int O) { return O <= 128 ? 2 : 1; }      // row groups per block (a block has at most 8 waves)
+
+// real blocks of a launch = slab rows
+int wgrad_blocks(int64_t N, int O) {
+    const int rg = wgrad_groups(O);
+    return (wgrad_grid(N) + rg - 1) / rg;
+}
+
 int wgrad_launch(const WgPair& pp, int nprob, int O, int I, int grid, hipStream_t s) {
-    const int waves = (O + 31) / 32, ti = (I + 31) / 32;
+    const int waves = (O + 31) / 32, ti = (I + 31) / 32, rg = wgrad_groups(O);
     // (two problems: one after the other on the same grid when the grid fills the chip - side by side they measured 94 us
     //  against 2 x 28 - but side by side when there are only a few dozen blocks)
-    dim3 blk(waves * 64), gr(grid, (nprob > 1 && grid <= 128) ? 2 : 1);
+    dim3 blk(waves * 64 * rg), gr(grid, (nprob > 1 && grid * rg <= 128) ? 2 : 1);
+    const size_t lds = rg > 1 ? sizeof(float) * (size_t)waves * (ti * 16 + 1) * 64 : 0;
+#define KP_WG(T) do { \
+        if (rg > 1) { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)wgrad_kernel<T, 2>, lds)); \
+                      hipLaunchKernelGGL((wgrad_kernel<T, 2>), gr, blk, lds, s, pp, nprob); } \
+        else hipLaunchKernelGGL((wgrad_kernel<T, 1>), gr, blk, 0, s, pp, nprob); } while (0)
     switch (ti) {
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, gr, blk, 0, s, pp, nprob); break;
-        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, gr, blk, 0, s, pp, nprob); break;
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, gr, blk, 0, s, pp, nprob); break;
-        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, gr, blk, 0, s, pp, nprob); break;
-        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, gr, blk, 0, s, pp, nprob); break;
-        case 6: hipLaunchKernelGGL(wgrad_kernel<6>, gr, blk, 0, s, pp, nprob); break;
-        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, gr, blk, 0, s, pp, nprob); break;
-        default: hipLaunchKernelGGL(wgrad_kernel<8>, gr, blk, 0, s, pp, nprob); break;
+        case 1: KP_WG(1); break;
+        case 2: KP_WG(2); break;
+        case 3: KP_WG(3); break;
+        case 4: KP_WG(4); break;
+        case 5: KP_WG(5); break;
+        case 6: KP_WG(6); break;
+        case 7: KP_WG(7); break;
+        default: KP_WG(8); break;
     }
+#undef KP_WG
     KPGNN_LAUNCH_CHECK("wgrad_kernel");
     return KPGNN_OK;
 }
@@ -176,7 +216,7 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
     float* slab = (float*)d->workspace;
     WgPair pp;
     pp.q[0] = pp.q[1] = wgrad_params(d, slab, nw + d->O, 0);
-    const int grid = wgrad_grid(d->N);
+    const int grid = wgrad_blocks(d->N, d->O);
     hipStream_t s = (hipStream_t)stream;
     rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
     if (rc != KPGNN_OK) return rc;
@@ -197,7 +237,7 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
     WgPair pp;
     pp.q[0] = wgrad_params(a, slab, 2 * one, 0);
     pp.q[1] = wgrad_params(b, slab, 2 * one, one);
-    const int grid = wgrad_grid(a->N);
+    const int grid = wgrad_blocks(a->N, a->O);
     hipStream_t s = (hipStream_t)stream;
     rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
     if (rc != KPGNN_OK) return rc;
