@@ -58,7 +58,7 @@ class TableGradDesc(ctypes.Structure):
         ("extra_slab", c_vp), ("extra_nslab", c_i32), ("extra_elems", c_i64), ("extra_out", c_vp), ("storage", c_i32),
         ("fuse_pre", c_vp), ("fuse_ptab", c_vp), ("fuse_uid", c_vp), ("fuse_uid_stride", c_i64), ("fuse_n_dict", c_i32),
         ("fuse_g", c_vp), ("fuse_gtheta", c_vp), ("fuse_alphas", c_vp), ("fuse_galphas", c_vp),
-        ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t),
+        ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t), ("accumulate_dict", c_i32),
     ]
 
 

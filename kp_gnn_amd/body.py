@@ -319,7 +319,11 @@ class _KHopBody(nn.Module):
         if uidx is not None:
             # dictionary form: the distinct index tuples are few (25 for a 2048-molecule batch), so P is a
             # [U,W] table + a static int32 uid per (node,hop); the layers' kernels read / differentiate that
-            return DictPeripheral(table_gather_sum(table, bias, uidx, col_offset), uid)
+            ptab = table_gather_sum(table, bias, uidx, col_offset)
+            # (every layer of the stack reads this table, one after the other: its gradient is collected in one buffer -
+            #  ops.KHopAggregate, dict_cell)
+            ptab._kp_shared_grad = True
+            return DictPeripheral(ptab, uid)
         return table_gather_sum(table, bias, idx, col_offset).view(num_nodes, -1, W)
 
     def _vn_init(self, batch, edge_index):

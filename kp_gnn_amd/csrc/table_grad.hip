@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(1024)
 slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, float* __restrict__ out0, int64_t n_out0,
                    float* __restrict__ out1, int64_t n_out1, float* __restrict__ out2, int64_t n_out2,
                    float* __restrict__ out3, int nblocks_a, const float* __restrict__ slab_b, int nslab_b, int64_t elems_b,
-                   float* __restrict__ out_b, int nblocks_ab, const ThetaFinish tf) {
+                   float* __restrict__ out_b, int nblocks_ab, const ThetaFinish tf, int acc_mask) {
     __shared__ float sm[1168];
     if ((int)blockIdx.x >= nblocks_ab) {   // the last blocks finish a theta-gradient slab (kpgnn_common.h)
         theta_finish_block(tf, (int)blockIdx.x - nblocks_ab, sm);
@@ -540,10 +540,13 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
     float (*part)[17] = reinterpret_cast<float (*)[17]>(sm);      // [64][17]
     const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
     int64_t blk = blockIdx.x;
+    bool acc2 = (acc_mask & 1) != 0;       // out2 += (the third output), bit 1: out_b +=
     if (blk >= nblocks_a) {           // the blocks behind the first slab's reduce a second, independent slab into out_b
         blk -= nblocks_a;
         slab = slab_b; nslab = nslab_b; elems = elems_b;
         out0 = out_b; n_out0 = elems_b;
+        acc2 = false;
+        if (acc_mask & 2) { out2 = out_b; n_out0 = 0; n_out1 = 0; n_out2 = elems_b; acc2 = true; }
     }
     const int64_t e = blk * 16 + o;
     float s = 0.f;
@@ -564,7 +567,7 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
         for (int q = 0; q < 64; ++q) tot += part[q][o];
         if (e < n_out0) out0[e] = tot;
         else if (e < n_out0 + n_out1) out1[e - n_out0] = tot;
-        else if (e < n_out0 + n_out1 + n_out2) out2[e - n_out0 - n_out1] = tot;
+        else if (e < n_out0 + n_out1 + n_out2) { float* q = out2 + (e - n_out0 - n_out1); *q = acc2 ? *q + tot : tot; }
         else out3[e - n_out0 - n_out1 - n_out2] = tot;
     }
 }
@@ -573,7 +576,7 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
 
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2, float* out3, const float* slab_b, int nslab_b, int64_t elems_b,
-                float* out_b, const ThetaFinish* tf) {
+                float* out_b, const ThetaFinish* tf, int acc_mask) {
     if (!slab_b || elems_b <= 0) { slab_b = nullptr; elems_b = 0; }
     if (elems < 0) elems = 0;
     ThetaFinish f;
@@ -589,7 +592,7 @@ int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_
     if (!out3) n2 = elems;   // three outputs: the rest goes to out2
     const int nba = (int)((elems + 15) / 16), nbb = (int)((elems_b + 15) / 16);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nba + nbb + nbt)), dim3(1024), 0, s, slab, nslab, elems,
-                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b, nba + nbb, f);
+                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b, nba + nbb, f, acc_mask);
     KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
     return KPGNN_OK;
 }
@@ -718,7 +721,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // ONE finishing launch: table slabs, the dictionary-gradient slab a kpgnn_dict_grad left behind, the theta gradient
         return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
                            (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out,
-                           d->fuse_gtheta ? &tf : nullptr);
+                           d->fuse_gtheta ? &tf : nullptr, d->accumulate_dict ? 3 : 0);
     }
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
@@ -732,6 +735,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(force != 1 || walk_fits, "table_grad: the walk kernel needs K <= 8, tiles of <= 64 (node, hop) rows and, "
                       "with a dictionary, the uid-sorted list of kpgnn_dict_tile_pack");
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
+            if (d->accumulate_dict) return fail(KPGNN_EINVAL, "table_grad: accumulate_dict is served by the walk kernel only");
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
             if (rc != KPGNN_OK) return rc;
@@ -766,5 +770,6 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     else rc = vec4 ? launch_walk<1, true>(p, pl, s) : launch_walk<1, false>(p, pl, s);
     if (rc != KPGNN_OK) return rc;
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
-                       (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out);
+                       (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out,
+                       nullptr, d->accumulate_dict ? 3 : 0);
 }

@@ -383,13 +383,14 @@ def _combine_table_grad_ok(csr, pre, table_rows=0, dict_rows=0):
 
 
 def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None,
-                           dict_rows=0):
+                           dict_rows=0, gdict_acc=None):
     """kpgnn_table_grad with the combine backward fused in (KP-GIN+ epilogue, fp32): computes g = theta[k]*gh[i]*gelu'(S[i,k]),
     the edge-code table gradients from it and (want_gtheta) the theta gradient / d/dalphas - `g` is written once and never read
     back for the tables.  Returns (g, gtheta or (gtheta, galphas) or None, gtable0, gtablek), or None when the shape has no
     fused kernel (the caller then runs combine_bwd_raw + table_grad_raw).
     dict_rows > 0: the dictionary gradient (theta[k]*gh[i] per (node, hop) id) rides along the walk and is returned as a
-    fifth value (small batches, where a separate dict_grad launch costs more than it saves)."""
+    fifth value (small batches, where a separate dict_grad launch costs more than it saves).
+    gdict_acc: a [n_dict, D] buffer the dictionary gradient (in-walk or `extra`) is ADDED to instead of being written."""
     lib = _lib.load()
     N, K, D = pre.shape
     dev = pre.device
@@ -407,9 +408,12 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
     d = _lib.TableGradDesc()
     d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, nk
     if dict_rows > 0:
-        gd = torch.empty((dict_rows, D), dtype=torch.float32, device=dev)
+        gd = torch.empty((dict_rows, D), dtype=torch.float32, device=dev) if gdict_acc is None else gdict_acc
         d.n_dict, d.dict_src, d.uid, d.uid_stride, d.gdict = dict_rows, 1, uid.data_ptr(), uid.stride(0), gd.data_ptr()
         d.dict_pack, d.dict_pack_K = pack.data_ptr(), kf
+    if gdict_acc is not None:
+        assert gdict_acc.is_contiguous() and gdict_acc.dtype == torch.float32 and (dict_rows > 0 or extra is not None)
+        d.accumulate_dict = 1
     tptr, tpack = csr.tile_list(K)
     d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
     d.g_sn, d.g_sk = K * D, D
@@ -435,7 +439,9 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
             gal = torch.empty_like(alphas)
             d.fuse_alphas, d.fuse_galphas = alphas.data_ptr(), gal.data_ptr()
     if extra is not None:
-        d.extra_out, d.extra_slab, d.extra_nslab, d.extra_elems = extra[0].data_ptr(), extra[1].data_ptr(), extra[2], extra[0].numel()
+        eo = extra[0] if gdict_acc is None else gdict_acc
+        assert eo.numel() == extra[0].numel()
+        d.extra_out, d.extra_slab, d.extra_nslab, d.extra_elems = eo.data_ptr(), extra[1].data_ptr(), extra[2], extra[0].numel()
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -532,6 +538,15 @@ class KHopAggregate(torch.autograd.Function):
         if periph is not None:
             periph = _last_contig(periph.float())
             ptab = uid = None
+        # a dictionary every layer of a sequential stack reads (the bodies mark it, body._peripheral): its gradient is collected
+        # in ONE buffer.  The first reader in forward order is the last to run backward: it hands autograd the total.
+        ctx.dict_cell, ctx.dict_first = None, False
+        if ptab is not None and getattr(ptab, "_kp_shared_grad", False):
+            c = getattr(ptab, "_kp_grad_cell", None)
+            ctx.dict_first = c is None
+            if c is None:
+                c = ptab._kp_grad_cell = _SlotGradCell()
+            ctx.dict_cell = c
         if table0 is not None:
             table0 = table0.contiguous()
             tablek = tablek.contiguous() if tablek is not None else None
@@ -572,7 +587,7 @@ class KHopAggregate(torch.autograd.Function):
         need_act = mode in (MODE_GINPLUS, MODE_GCN)
         want_gperiph = ctx.has_periph and ctx.needs_input_grad[3]
         want_gdict = ctx.n_dict > 0 and ctx.needs_input_grad[7]
-        gtheta = gperiph = gdict = None
+        gtheta = gperiph = gdict = acc = None
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
@@ -584,12 +599,15 @@ class KHopAggregate(torch.autograd.Function):
         if (fused and mode == MODE_GINPLUS and want_tables and periph is None and not want_gperiph
                 and _combine_table_grad_ok(csr, pre, ctx.n_code0 + (ctx.n_codek if k_act > 1 else 0), ctx.n_dict)):
             extra = dg = None
+            if want_gdict and ctx.dict_cell is not None and ctx.dict_cell.buf is not None:
+                acc = ctx.dict_cell.buf                       # later layers' share: the finishing launch adds to it
             if want_gdict and pre.shape[0] >= 4096:
                 dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)
                 extra = dg
             in_walk = ctx.n_dict if (want_gdict and dg is None) else 0   # small batches: the dictionary rows ride along
             r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
-                                       want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra, dict_rows=in_walk)
+                                       want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra, dict_rows=in_walk,
+                                       gdict_acc=acc)
             if r is None and in_walk:
                 r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
                                            want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas)
@@ -600,9 +618,11 @@ class KHopAggregate(torch.autograd.Function):
                     gtheta = gtheta[1]
                     galphas_done = True
                 if dg is not None:
-                    gdict = dg[0]
+                    gdict = dg[0] if acc is None else acc
+                    acc = None
                 elif in_walk:
                     gdict = r[4]
+                    acc = None
                 elif want_gdict:
                     gdict = table_grad_raw(csr, g, 0, 0, edges=False, uid=uid, n_dict=ctx.n_dict, theta=theta, gh=gout)[2]
                 done = True
@@ -656,6 +676,15 @@ class KHopAggregate(torch.autograd.Function):
                     raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
+        if ctx.dict_cell is not None and want_gdict:
+            if acc is None and not done and ctx.dict_cell.buf is not None:
+                acc = ctx.dict_cell.buf
+            if acc is not None:                      # (a path without the accumulating launch: add the parked share the plain way)
+                gdict = gdict + acc
+            if ctx.dict_first:
+                ctx.dict_cell.buf = None             # the total goes to autograd
+            else:
+                ctx.dict_cell.buf, gdict = gdict, None
         xbuf = None
         if (ctx.x_cell is not None and ctx.x_cell.buf is not None and ctx.needs_input_grad[0] and k_act <= 32
                 and mode != MODE_GCN and not tables_in_gather):

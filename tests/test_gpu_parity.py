@@ -1399,3 +1399,42 @@ def test_copy_grads_is_exact_and_replays_in_a_graph():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(flat, torch.cat([torch.zeros(3, device=DEV)] + grads))      # the doubled sources
+
+
+@pytest.mark.parametrize("N", [700, 5000])
+def test_shared_dictionary_gradient_cell_equals_autograd_sum(N):
+    """A dictionary marked _kp_shared_grad and read by three layers in sequence (hop prefixes 2, 4, 6) collects its gradient
+    in one buffer (kpgnn_table_grad accumulate_dict: in the walk at N = 700, through the deferred dict_grad slab at N = 5000)
+    and the first reader hands autograd the total: equal to the unmarked run, where autograd sums three tensors."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    E, K, D, U = 12 * N, 6, 104, 11
+    g0 = torch.Generator().manual_seed(N)
+    ei = torch.randint(0, N, (2, E), generator=g0)
+    ea = torch.randint(1, 7, (E, K), generator=g0) * (torch.rand(E, K, generator=g0) < 0.4)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    base = dict(x=torch.randn(N, D, generator=g0), t0=torch.randn(7, D, generator=g0) * 0.3,
+                tk=torch.randn(7, D, generator=g0) * 0.3, ptab=torch.randn(U, D, generator=g0), alphas=torch.randn(D, generator=g0))
+    uid = torch.randint(0, U, (N, K), generator=g0, dtype=torch.int32).to(dev)
+    w = torch.randn(N, D, generator=g0).to(dev)
+
+    def run(shared):
+        t = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        ptab = t["ptab"] * 1.0                     # (a non-leaf, as in the bodies)
+        if shared:
+            ptab._kp_shared_grad = True
+        periph = ops.DictPeripheral(ptab, uid)
+        states = [t["x"]]
+        for k in (2, 4, 6):
+            slots = [states[-1]] * k
+            h = ops.khop_aggregate(slots, csr, k, ops.MODE_GINPLUS, t["t0"], t["tk"], periph[:, :k], theta=t["alphas"])
+            states.append(torch.tanh(h))
+        (states[-1] * w).sum().backward()
+        cell = getattr(ptab, "_kp_grad_cell", None)
+        assert (cell is not None) == shared and (cell is None or cell.buf is None)
+        return t
+
+    a, b = run(True), run(False)
+    for k in base:
+        _close(a[k].grad, b[k].grad.cpu(), "grad " + k, rtol=2e-4, atol=2e-5)
