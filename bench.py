@@ -89,8 +89,8 @@ def build_model(args, device):
 
 
 def loss_of(args, score, y):
-    d = score.squeeze() - y.squeeze()
-    return d.abs().mean() if args.loss == "l1" else (d * d).mean()       # train_ZINC.py:42 / train_qm9.py:96
+    from kp_gnn_amd.ops_dense import regression_loss
+    return regression_loss(score, y, args.loss)                          # train_ZINC.py:42 / train_qm9.py:96
 
 
 def fwd_bwd(args, model, batch, flat_grad):

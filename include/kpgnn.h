@@ -90,6 +90,12 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
 int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t k,
                            int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
 
+/* loss[0] = mean_i |score[i] - y[i]| (kind 0; train_ZINC.py:42) or mean_i (score[i] - y[i])^2 (kind 1; train_qm9.py:96) and,
+ * when dscore != NULL, dscore[i] = d loss / d score[i].  score, y: device [n] contiguous.  One launch, one block, fixed
+ * summation order (bitwise reproducible); meant for batches of graph scores (n up to ~1e5). */
+int kpgnn_regression_loss(const float* score, const float* y, int64_t n, int32_t kind, float* loss, float* dscore,
+                          kpgnn_stream_t stream);
+
 /* count contiguous fp32 tensors copied device-to-device in ceil(count / 96) launches: dst[i][0..numel[i]) = src[i][..].  The
  * pointer tables are HOST arrays read at call time and passed to the kernel by value (capturable: a hipGraph node keeps
  * them).  Used to move a step's parameter gradients into their views of the flat all-reduce bucket (train_ZINC.py:34-36

@@ -52,21 +52,24 @@ def grad_views(model):
 
 def copy_grads(views, grads):
     """views[i].copy_(grads[i]) for all i in one or two launches (kpgnn_multi_copy; the pointer table rides in the kernel
-    arguments, so a captured graph replays it as is).  Falls back to the framework's multi-tensor copy for anything that is
-    not a contiguous fp32 CUDA tensor."""
+    arguments, so a captured graph replays it as is).  Pairs that are not contiguous fp32 CUDA tensors of equal size (a
+    transposed weight gradient, say) go through the framework's multi-tensor copy."""
     import ctypes
     from . import _lib
-    ok = views and all(v.is_cuda and g.is_cuda and v.dtype == torch.float32 and g.dtype == torch.float32 and v.is_contiguous()
-                       and g.is_contiguous() and v.numel() == g.numel() for v, g in zip(views, grads))
-    if not ok:
-        if views:
-            torch._foreach_copy_(list(views), list(grads))
+    fast, slow = [], []
+    for v, g in zip(views, grads):
+        ok = (v.is_cuda and g.is_cuda and v.dtype == torch.float32 and g.dtype == torch.float32 and v.is_contiguous()
+              and g.is_contiguous() and v.numel() == g.numel())
+        (fast if ok else slow).append((v, g))
+    if slow:
+        torch._foreach_copy_([v for v, _ in slow], [g for _, g in slow])
+    if not fast:
         return
-    n = len(views)
-    src = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
-    dst = (ctypes.c_void_p * n)(*[v.data_ptr() for v in views])
-    cnt = (ctypes.c_int64 * n)(*[v.numel() for v in views])
-    dev = views[0].device
+    n = len(fast)
+    src = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in fast])
+    dst = (ctypes.c_void_p * n)(*[v.data_ptr() for v, _ in fast])
+    cnt = (ctypes.c_int64 * n)(*[v.numel() for v, _ in fast])
+    dev = fast[0][0].device
     with torch.cuda.device(dev):
         _lib.check(_lib.load().kpgnn_multi_copy(n, src, dst, cnt, torch.cuda.current_stream(dev).cuda_stream), "kpgnn_multi_copy")
 

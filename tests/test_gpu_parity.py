@@ -1438,3 +1438,28 @@ def test_shared_dictionary_gradient_cell_equals_autograd_sum(N):
     a, b = run(True), run(False)
     for k in base:
         _close(a[k].grad, b[k].grad.cpu(), "grad " + k, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [1, 64, 2048, 5001])
+@pytest.mark.parametrize("kind", ["l1", "mse"])
+def test_regression_loss_vs_framework_ops(n, kind):
+    """kpgnn_regression_loss (train_ZINC.py:42 / train_qm9.py:96) against the framework's ops on the CPU: value and gradient,
+    including exact zeros of score - y (sign(0) = 0); two launches give the same bits."""
+    from kp_gnn_amd.ops_dense import regression_loss
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    score = torch.randn(n, 1, generator=g) * 3
+    y = torch.randn(n, generator=g)
+    if n > 3:
+        score[2, 0] = y[2]
+    sd = score.to(dev).requires_grad_(True)
+    loss = regression_loss(sd, y.to(dev), kind)
+    loss2 = regression_loss(sd.detach(), y.to(dev), kind)
+    assert torch.equal(loss.detach(), loss2)
+    (loss * 1.5).backward()
+    sr = score.clone().requires_grad_(True)
+    d = sr.squeeze(-1) - y
+    ref = d.abs().mean() if kind == "l1" else (d * d).mean()
+    (ref * 1.5).backward()
+    _close(loss, ref, "loss", rtol=1e-5, atol=1e-6)
+    _close(sd.grad, sr.grad, "dscore", rtol=1e-6, atol=1e-7)
