@@ -100,9 +100,11 @@ def fwd_bwd(args, model, batch, flat_grad):
     if not args.train:
         with torch.no_grad():
             return model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
-    loss = loss_of(args, model(batch), batch.y)
+    from kp_gnn_amd.ops_dense import regression_loss_and_grad
+    score = model(batch)
+    loss, dscore = regression_loss_and_grad(score, batch.y, args.loss)   # train_ZINC.py:42 / train_qm9.py:96, with its gradient
     params, views = dp.grad_views(model)
-    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    grads = torch.autograd.grad(score, params, grad_outputs=dscore, allow_unused=True)
     used = [(v, g) for v, g in zip(views, grads) if g is not None]
     dp.copy_grads([v for v, _ in used], [g for _, g in used])
     # (parameters without a gradient - e.g. the never-trained path-encoding tables, Q1 - keep the zeros the flat bucket
@@ -327,7 +329,7 @@ def main():
         flat_grad = dp.flatten_grads(model)
         flat_param = dp.flatten_params(model)     # parameters and gradients: one flat bucket each (same order)
         flat_param.grad = flat_grad
-        opt = torch.optim.Adam([flat_param], lr=1e-3, fused=True, capturable=True)   # elementwise: identical to per-parameter Adam
+        opt = dp.FlatAdam(flat_param, flat_grad, lr=1e-3)    # elementwise: identical to per-parameter Adam (train_ZINC.py:244)
 
     def barrier():
         torch.cuda.synchronize()

@@ -96,6 +96,12 @@ int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, i
 int kpgnn_regression_loss(const float* score, const float* y, int64_t n, int32_t kind, float* loss, float* dscore,
                           kpgnn_stream_t stream);
 
+/* One torch.optim.Adam step (amsgrad off, L2 weight_decay as in train_ZINC.py:244) over a flat bucket of n fp32
+ * parameters with its gradient and the two moment buffers (all device, 16-B aligned, updated in place); step = 1 for the
+ * first call.  Elementwise, so stepping the flat bucket of dp.py equals stepping the ~190 tensors one by one. */
+int kpgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, kpgnn_stream_t stream);
+
 /* count contiguous fp32 tensors copied device-to-device in ceil(count / 96) launches: dst[i][0..numel[i]) = src[i][..].  The
  * pointer tables are HOST arrays read at call time and passed to the kernel by value (capturable: a hipGraph node keeps
  * them).  Used to move a step's parameter gradients into their views of the flat all-reduce bucket (train_ZINC.py:34-36

@@ -203,6 +203,8 @@ SIGNATURES = {
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_regression_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, c_vp]),
     "kpgnn_multi_copy": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),

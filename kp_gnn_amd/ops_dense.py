@@ -609,6 +609,21 @@ class RegressionLoss(torch.autograd.Function):
         return (ds * gout).view(ctx.shape) if ds is not None else None, None, None
 
 
+def regression_loss_and_grad(score, y, kind="l1"):
+    """(loss, d loss / d score) of regression_loss from its one launch, for a caller that seeds the backward pass itself
+    (torch.autograd.grad(score, params, grad_outputs=dscore)): the ones-fill and the multiply by it never run."""
+    with torch.no_grad():
+        s = score.detach().reshape(-1).contiguous()
+        t = y.reshape(-1).to(torch.float32).contiguous()
+        assert s.is_cuda and s.dtype == torch.float32 and s.numel() == t.numel() and s.numel() >= 1
+        loss = torch.empty((), dtype=torch.float32, device=s.device)
+        ds = torch.empty_like(s)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.load().kpgnn_regression_loss(s.data_ptr(), t.data_ptr(), s.numel(), 0 if kind == "l1" else 1,
+                                                         loss.data_ptr(), ds.data_ptr(), _stream(s)), "kpgnn_regression_loss")
+    return loss, ds.view(score.shape)
+
+
 def regression_loss(score, y, kind="l1"):
     """The training scripts' loss on a batch of graph scores: kind "l1" = (score.squeeze() - y.squeeze()).abs().mean()
     (train_ZINC.py:42), "mse" = its squared counterpart (train_qm9.py:96)."""

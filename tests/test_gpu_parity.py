@@ -1463,3 +1463,31 @@ def test_regression_loss_vs_framework_ops(n, kind):
     (ref * 1.5).backward()
     _close(loss, ref, "loss", rtol=1e-5, atol=1e-6)
     _close(sd.grad, sr.grad, "dscore", rtol=1e-6, atol=1e-7)
+    from kp_gnn_amd.ops_dense import regression_loss_and_grad
+    l3, ds = regression_loss_and_grad(sd, y.to(dev), kind)
+    assert torch.equal(l3, loss.detach()) and ds.shape == sd.shape
+    _close(ds * 1.5, sr.grad, "dscore (seed form)", rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_flat_adam_equals_framework_adam(wd):
+    """dp.FlatAdam (kpgnn_adam_step) on a flat bucket against torch.optim.Adam on the same numbers, five steps with fresh
+    gradients (n not a multiple of 4: the scalar tail)."""
+    from kp_gnn_amd import dp
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n = 70003
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt_ref = torch.optim.Adam([ref], lr=1e-2, weight_decay=wd)
+    flat_p, flat_g = torch.nn.Parameter(p0.clone().to(dev)), torch.zeros(n, device=dev)
+    opt = dp.FlatAdam(flat_p, flat_g, lr=1e-2, weight_decay=wd)
+    for _ in range(5):
+        grad = torch.randn(n, generator=g) * torch.rand(n, generator=g) ** 4
+        ref.grad = grad.clone()
+        flat_g.copy_(grad.to(dev))
+        opt_ref.step()
+        opt.step()
+    _close(flat_p, ref, "param after 5 steps", rtol=1e-5, atol=1e-6)
+    _close(opt.exp_avg, opt_ref.state[ref]["exp_avg"], "exp_avg", rtol=1e-5, atol=1e-7)
+    _close(opt.exp_avg_sq, opt_ref.state[ref]["exp_avg_sq"], "exp_avg_sq", rtol=1e-5, atol=1e-9)
