@@ -104,7 +104,9 @@ def fwd_bwd(args, model, batch, flat_grad):
     score = model(batch)
     loss, dscore = regression_loss_and_grad(score, batch.y, args.loss)   # train_ZINC.py:42 / train_qm9.py:96, with its gradient
     params, views = dp.grad_views(model)
-    grads = torch.autograd.grad(score, params, grad_outputs=dscore, allow_unused=True)
+    from kp_gnn_amd import ops
+    with ops.deferred_reductions():      # (gradients are read after the block: the weight-gradient reduces ride along)
+        grads = torch.autograd.grad(score, params, grad_outputs=dscore, allow_unused=True)
     used = [(v, g) for v, g in zip(views, grads) if g is not None]
     dp.copy_grads([v for v, _ in used], [g for _, g in used])
     # (parameters without a gradient - e.g. the never-trained path-encoding tables, Q1 - keep the zeros the flat bucket

@@ -102,11 +102,23 @@ int kpgnn_regression_loss(const float* score, const float* y, int64_t n, int32_t
 int kpgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                     double lr, double beta1, double beta2, double eps, double weight_decay, kpgnn_stream_t stream);
 
-/* count contiguous fp32 tensors copied device-to-device in ceil(count / 96) launches: dst[i][0..numel[i]) = src[i][..].  The
+/* count contiguous fp32 tensors copied device-to-device in ceil(count / 192) launches: dst[i][0..numel[i]) = src[i][..].  The
  * pointer tables are HOST arrays read at call time and passed to the kernel by value (capturable: a hipGraph node keeps
  * them).  Used to move a step's parameter gradients into their views of the flat all-reduce bucket (train_ZINC.py:34-36
  * leaves that to DataParallel's per-tensor reduce). */
 int kpgnn_multi_copy(int32_t count, const float* const* src, float* const* dst, const int64_t* numel, kpgnn_stream_t stream);
+
+/* A reduction that a launch left for later: slab holds nslab rows of elems partial sums (block order); the finished sums
+ * out[e] = sum_b slab[b][e] go, in order, to n_out[0] elements of out[0], n_out[1] of out[1], ... (sum n_out == elems).
+ * kpgnn_linear_wgrad(_pair) fills one instead of launching its own reduce when desc.defer is set; the caller hands it to the
+ * next call that has a finishing launch anyway (kpgnn_table_grad_desc.pending) or runs it with kpgnn_reduce_jobs.  The slab
+ * (the producing call's workspace) must stay untouched until then.  Fixed summation order: the result does not depend on
+ * which launch does the adding. */
+typedef struct kpgnn_reduce_job {
+    const float* slab; int32_t nslab; int64_t elems;
+    float* out[4]; int64_t n_out[4];
+} kpgnn_reduce_job;
+int kpgnn_reduce_jobs(const kpgnn_reduce_job* jobs, int32_t count, kpgnn_stream_t stream);   /* ceil(count / 3) launches */
 
 /* ------------------------------------------------------------------------------------------------
  * Fused K-hop aggregation.
@@ -278,6 +290,8 @@ typedef struct kpgnn_table_grad_desc {
      * dictionary read by every layer collects its gradient in one buffer instead of one tensor per layer for the
      * framework to sum (7 add launches per step at L = 8). */
     int32_t accumulate_dict;
+    /* Optional (host pointer): one deferred reduction of an earlier call, added up by this call's finishing launch. */
+    const kpgnn_reduce_job* pending;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
@@ -464,6 +478,10 @@ typedef struct kpgnn_wgrad_desc {
      * input when that was a BatchNorm(+ReLU) output the forward never materialised (kpgnn_linear_bn pro 1). */
     const float* x_mean; const float* x_invstd; const float* x_gamma; const float* x_beta;   /* device [I] or all NULL */
     int32_t x_relu;
+    /* Optional (host pointer): leave the per-block partials in `workspace` and describe their reduction here instead of
+     * launching it (kpgnn_reduce_job above; for kpgnn_linear_wgrad_pair: a->defer, one job for all four outputs).  dw / db
+     * are NOT written until the job has run. */
+    kpgnn_reduce_job* defer;
 } kpgnn_wgrad_desc;
 
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);

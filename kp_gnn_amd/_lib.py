@@ -59,6 +59,7 @@ class TableGradDesc(ctypes.Structure):
         ("fuse_pre", c_vp), ("fuse_ptab", c_vp), ("fuse_uid", c_vp), ("fuse_uid_stride", c_i64), ("fuse_n_dict", c_i32),
         ("fuse_g", c_vp), ("fuse_gtheta", c_vp), ("fuse_alphas", c_vp), ("fuse_galphas", c_vp),
         ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t), ("accumulate_dict", c_i32),
+        ("pending", c_vp),
     ]
 
 
@@ -104,12 +105,17 @@ class BnBwdDesc(ctypes.Structure):
     ]
 
 
+class ReduceJob(ctypes.Structure):
+    _fields_ = [("slab", c_vp), ("nslab", c_i32), ("elems", c_i64), ("out", c_vp * 4), ("n_out", c_i64 * 4)]
+
+
 class WgradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("dy", c_vp), ("dy_stride", c_i64), ("x", c_vp), ("x_stride", c_i64),
         ("dw", c_vp), ("db", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("x_mean", c_vp), ("x_invstd", c_vp), ("x_gamma", c_vp), ("x_beta", c_vp), ("x_relu", c_i32),
+        ("defer", c_vp),
     ]
 
 
@@ -205,6 +211,7 @@ SIGNATURES = {
     "kpgnn_regression_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_double, c_vp]),
+    "kpgnn_reduce_jobs": (ctypes.c_int, [c_vp, c_i32, c_vp]),
     "kpgnn_multi_copy": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),

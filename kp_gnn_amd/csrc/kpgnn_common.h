@@ -66,7 +66,8 @@ struct ThetaFinish {
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2 = 0, float* out3 = nullptr, const float* slab_b = nullptr,
                 int nslab_b = 0, int64_t elems_b = 0, float* out_b = nullptr, const ThetaFinish* tf = nullptr,
-                int acc_mask = 0);   // bit 0: out2 += , bit 1: out_b +=  (a gradient collected over several calls)
+                int acc_mask = 0,    // bit 0: out2 += , bit 1: out_b +=  (a gradient collected over several calls)
+                const kpgnn_reduce_job* pending = nullptr);   // a third, caller-described job (kpgnn.h)
 
 // A 1024-thread block's share of the theta finishing (block `blk` owns CB = 64 / K columns); sm: >= 1168 floats of LDS.
 __device__ __forceinline__ void theta_finish_block(const ThetaFinish& f, int blk, float* sm) {

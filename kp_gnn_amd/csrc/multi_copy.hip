@@ -10,7 +10,7 @@
 namespace kpgnn {
 namespace {
 
-constexpr int kMcMax = 96;            // 96 * (8 + 8 + 4) B = 1.9 KB of kernel arguments
+constexpr int kMcMax = 192;           // 192 * (8 + 8 + 4) B = 3.8 KB of kernel arguments (the limit is 4 KB)
 constexpr int kMcChunk = 1024;        // floats per block
 
 struct McArgs {

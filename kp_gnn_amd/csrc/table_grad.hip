@@ -526,29 +526,33 @@ dict_tile_pack_kernel(const int32_t* __restrict__ uid, int64_t uid_stride, int N
 }
 
 // out[e] = sum_b slab[b][e]   (fixed order: deterministic).  16 outputs x 64 slices of the slab range per WG: each
-// thread adds nslab/64 values (independent loads), the 64 partials of an output meet in LDS.
+// thread adds nslab/64 values (independent loads), the 64 partials of an output meet in LDS.  A launch works through up
+// to three independent jobs (block ranges one after the other) and a theta-gradient finish.
+struct SlabJob {
+    const float* slab; int nslab; int nblocks; int acc;    // acc bit i: out[i] += instead of =
+    int64_t elems;
+    float* out[4]; int64_t n[3];                            // outputs [0, n0) -> out[0], [n0, n0+n1) -> out[1], ... rest -> out[3]
+};
+struct SlabArgs { SlabJob j[3]; ThetaFinish tf; };
+
 __global__ void __launch_bounds__(1024)
-slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, float* __restrict__ out0, int64_t n_out0,
-                   float* __restrict__ out1, int64_t n_out1, float* __restrict__ out2, int64_t n_out2,
-                   float* __restrict__ out3, int nblocks_a, const float* __restrict__ slab_b, int nslab_b, int64_t elems_b,
-                   float* __restrict__ out_b, int nblocks_ab, const ThetaFinish tf, int acc_mask) {
+slab_reduce_kernel(const SlabArgs a) {
     __shared__ float sm[1168];
-    if ((int)blockIdx.x >= nblocks_ab) {   // the last blocks finish a theta-gradient slab (kpgnn_common.h)
-        theta_finish_block(tf, (int)blockIdx.x - nblocks_ab, sm);
+    int blk = blockIdx.x;
+    int ji = 0;
+    while (ji < 3 && blk >= a.j[ji].nblocks) { blk -= a.j[ji].nblocks; ++ji; }
+    if (ji == 3) {                      // the last blocks finish a theta-gradient slab (kpgnn_common.h)
+        theta_finish_block(a.tf, blk, sm);
         return;
     }
+    // (the job is picked with uniform selects, not by indexing the argument struct with a runtime value)
+    const SlabJob& J = ji == 0 ? a.j[0] : (ji == 1 ? a.j[1] : a.j[2]);
+    const float* __restrict__ slab = J.slab;
+    const int nslab = J.nslab;
+    const int64_t elems = J.elems;
     float (*part)[17] = reinterpret_cast<float (*)[17]>(sm);      // [64][17]
     const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    int64_t blk = blockIdx.x;
-    bool acc2 = (acc_mask & 1) != 0;       // out2 += (the third output), bit 1: out_b +=
-    if (blk >= nblocks_a) {           // the blocks behind the first slab's reduce a second, independent slab into out_b
-        blk -= nblocks_a;
-        slab = slab_b; nslab = nslab_b; elems = elems_b;
-        out0 = out_b; n_out0 = elems_b;
-        acc2 = false;
-        if (acc_mask & 2) { out2 = out_b; n_out0 = 0; n_out1 = 0; n_out2 = elems_b; acc2 = true; }
-    }
-    const int64_t e = blk * 16 + o;
+    const int64_t e = (int64_t)blk * 16 + o;
     float s = 0.f;
     if (e < elems) {
         int b = slice;
@@ -565,35 +569,98 @@ slab_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t elems, flo
         float tot = 0.f;
 #pragma unroll
         for (int q = 0; q < 64; ++q) tot += part[q][o];
-        if (e < n_out0) out0[e] = tot;
-        else if (e < n_out0 + n_out1) out1[e - n_out0] = tot;
-        else if (e < n_out0 + n_out1 + n_out2) { float* q = out2 + (e - n_out0 - n_out1); *q = acc2 ? *q + tot : tot; }
-        else out3[e - n_out0 - n_out1 - n_out2] = tot;
+        int which = 3;
+        int64_t off = e;
+        if (off < J.n[0]) which = 0;
+        else if ((off -= J.n[0]) < J.n[1]) which = 1;
+        else if ((off -= J.n[1]) < J.n[2]) which = 2;
+        else off -= J.n[2];
+        float* q = (which == 0 ? J.out[0] : which == 1 ? J.out[1] : which == 2 ? J.out[2] : J.out[3]) + off;
+        *q = ((J.acc >> which) & 1) ? *q + tot : tot;
     }
+}
+
+SlabJob empty_job() {
+    SlabJob j;
+    j.slab = nullptr; j.nslab = 0; j.nblocks = 0; j.acc = 0; j.elems = 0;
+    for (int i = 0; i < 4; ++i) j.out[i] = nullptr;
+    j.n[0] = j.n[1] = j.n[2] = 0;
+    return j;
+}
+
+int public_job(const kpgnn_reduce_job* r, SlabJob* j) {
+    *j = empty_job();
+    if (!r || !r->slab || r->elems <= 0) return KPGNN_OK;
+    int64_t tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        KPGNN_REQUIRE(r->n_out[i] >= 0 && (r->n_out[i] == 0 || r->out[i]), "reduce job: output %d is NULL", i);
+        tot += r->n_out[i];
+    }
+    KPGNN_REQUIRE(tot == r->elems && r->nslab >= 1, "reduce job: the outputs cover %lld of %lld elements (nslab %d)",
+                  (long long)tot, (long long)r->elems, r->nslab);
+    j->slab = r->slab; j->nslab = r->nslab; j->elems = r->elems; j->nblocks = (int)((r->elems + 15) / 16);
+    for (int i = 0; i < 4; ++i) j->out[i] = r->out[i];
+    for (int i = 0; i < 3; ++i) j->n[i] = r->n_out[i];
+    return KPGNN_OK;
+}
+
+int launch_slab(const SlabArgs& a, int nbt, hipStream_t s) {
+    const int64_t blocks = (int64_t)a.j[0].nblocks + a.j[1].nblocks + a.j[2].nblocks + nbt;
+    if (blocks == 0) return KPGNN_OK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, a);
+    KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
+    return KPGNN_OK;
 }
 
 }  // namespace
 
 int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_t n0, float* out1, int64_t n1,
                 float* out2, hipStream_t s, int64_t n2, float* out3, const float* slab_b, int nslab_b, int64_t elems_b,
-                float* out_b, const ThetaFinish* tf, int acc_mask) {
+                float* out_b, const ThetaFinish* tf, int acc_mask, const kpgnn_reduce_job* pending) {
     if (!slab_b || elems_b <= 0) { slab_b = nullptr; elems_b = 0; }
     if (elems < 0) elems = 0;
-    ThetaFinish f;
-    f.slab = nullptr; f.nslab = 0; f.alpha = f.theta = nullptr; f.K = 1; f.D = 0; f.gtheta = f.galpha = nullptr;
+    SlabArgs a;
+    a.tf.slab = nullptr; a.tf.nslab = 0; a.tf.alpha = a.tf.theta = nullptr; a.tf.K = 1; a.tf.D = 0; a.tf.gtheta = a.tf.galpha = nullptr;
     int nbt = 0;
     if (tf && tf->slab && tf->D > 0) {
         if (tf->K > 64) return fail(KPGNN_ELIMIT, "slab_reduce: theta finishing needs K <= 64 (K = %d)", tf->K);
-        f = *tf;
-        const int CB = 64 / f.K;
-        nbt = (f.D + CB - 1) / CB;
+        a.tf = *tf;
+        const int CB = 64 / a.tf.K;
+        nbt = (a.tf.D + CB - 1) / CB;
     }
-    if (elems <= 0 && elems_b <= 0 && nbt == 0) return KPGNN_OK;
     if (!out3) n2 = elems;   // three outputs: the rest goes to out2
-    const int nba = (int)((elems + 15) / 16), nbb = (int)((elems_b + 15) / 16);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nba + nbb + nbt)), dim3(1024), 0, s, slab, nslab, elems,
-                       out0, n0, out1, n1, out2, n2, out3, nba, slab_b, nslab_b, elems_b, out_b, nba + nbb, f, acc_mask);
-    KPGNN_LAUNCH_CHECK("slab_reduce_kernel");
+    a.j[0] = empty_job();
+    if (elems > 0) {
+        SlabJob& j = a.j[0];
+        j.slab = slab; j.nslab = nslab; j.elems = elems; j.nblocks = (int)((elems + 15) / 16);
+        j.out[0] = out0; j.out[1] = out1; j.out[2] = out2; j.out[3] = out3;
+        j.n[0] = n0; j.n[1] = n1; j.n[2] = n2;
+        j.acc = (acc_mask & 1) ? 4 : 0;           // bit 0 of acc_mask: the third output accumulates
+    }
+    a.j[1] = empty_job();
+    if (elems_b > 0) {
+        SlabJob& j = a.j[1];
+        j.slab = slab_b; j.nslab = nslab_b; j.elems = elems_b; j.nblocks = (int)((elems_b + 15) / 16);
+        j.out[0] = out_b; j.n[0] = elems_b;
+        j.acc = (acc_mask & 2) ? 1 : 0;
+    }
+    const int rc = public_job(pending, &a.j[2]);
+    if (rc != KPGNN_OK) return rc;
+    return launch_slab(a, nbt, s);
+}
+
+extern "C" int kpgnn_reduce_jobs(const kpgnn_reduce_job* jobs, int32_t count, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(count >= 0 && (count == 0 || jobs), "reduce_jobs: bad arguments");
+    for (int c0 = 0; c0 < count; c0 += 3) {
+        SlabArgs a;
+        a.tf.slab = nullptr; a.tf.nslab = 0; a.tf.alpha = a.tf.theta = nullptr; a.tf.K = 1; a.tf.D = 0; a.tf.gtheta = a.tf.galpha = nullptr;
+        for (int i = 0; i < 3; ++i) {
+            const int rc = public_job(c0 + i < count ? jobs + c0 + i : nullptr, &a.j[i]);
+            if (rc != KPGNN_OK) return rc;
+        }
+        const int rc = launch_slab(a, 0, (hipStream_t)stream);
+        if (rc != KPGNN_OK) return rc;
+    }
     return KPGNN_OK;
 }
 
@@ -721,7 +788,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // ONE finishing launch: table slabs, the dictionary-gradient slab a kpgnn_dict_grad left behind, the theta gradient
         return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
                            (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out,
-                           d->fuse_gtheta ? &tf : nullptr, d->accumulate_dict ? 3 : 0);
+                           d->fuse_gtheta ? &tf : nullptr, d->accumulate_dict ? 3 : 0, d->pending);
     }
     KPGNN_REQUIRE(d->g_sk == d->D && d->g_sn == (int64_t)d->K * d->D, "table_grad: g must be contiguous [N,K,D]");
     {   // Narrow rows (D <= 32: KP-GIN's dk = hidden / K) and shapes the walk kernel cannot tile (K > 8) go to the
@@ -740,8 +807,8 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
             const int rc = table_grad_mfma(d, s, &handled);
             if (rc != KPGNN_OK) return rc;
             if (handled)
-                return d->extra_slab ? slab_reduce(d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out, d->extra_elems,
-                                                   nullptr, 0, nullptr, s) : KPGNN_OK;
+                return slab_reduce(d->extra_slab, d->extra_slab ? d->extra_nslab : 0, d->extra_slab ? d->extra_elems : 0, d->extra_out,
+                                   d->extra_elems, nullptr, 0, nullptr, s, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, d->pending);
         }
     }
     TgParams p;
@@ -771,5 +838,5 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     if (rc != KPGNN_OK) return rc;
     return slab_reduce(p.slab, pl.grid_x, (int64_t)pl.R * p.D, d->gtable0, (int64_t)p.n0 * p.D, d->gtablek,
                        (int64_t)p.nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_elems, d->extra_out,
-                       nullptr, d->accumulate_dict ? 3 : 0);
+                       nullptr, d->accumulate_dict ? 3 : 0, d->pending);
 }

@@ -221,6 +221,13 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
     rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
     if (rc != KPGNN_OK) return rc;
     float* db = d->db ? d->db : slab + (size_t)kWgradBlocks * (nw + d->O);  // sink behind the slabs
+    if (d->defer) {
+        kpgnn_reduce_job* j = d->defer;
+        j->slab = slab; j->nslab = grid; j->elems = nw + d->O;
+        j->out[0] = d->dw; j->n_out[0] = nw; j->out[1] = db; j->n_out[1] = d->O;
+        j->out[2] = j->out[3] = nullptr; j->n_out[2] = j->n_out[3] = 0;
+        return KPGNN_OK;
+    }
     return slab_reduce(slab, grid, nw + d->O, d->dw, nw, db, d->O, nullptr, s);
 }
 
@@ -241,6 +248,13 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
     hipStream_t s = (hipStream_t)stream;
     rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
     if (rc != KPGNN_OK) return rc;
+    if (a->defer) {
+        kpgnn_reduce_job* j = a->defer;
+        j->slab = slab; j->nslab = grid; j->elems = 2 * one;
+        j->out[0] = a->dw; j->n_out[0] = nw; j->out[1] = a->db; j->n_out[1] = a->O;
+        j->out[2] = b->dw; j->n_out[2] = nw; j->out[3] = b->db; j->n_out[3] = b->O;
+        return KPGNN_OK;
+    }
     return slab_reduce(slab, grid, 2 * one, a->dw, nw, a->db, a->O, b->dw, s, nw, b->db);
 }
 

@@ -106,6 +106,57 @@ def _check_codes(csr, k_act, table0, tablek):
         raise IndexError(f"edge code {csr.max_codek} out of range for hopk_edge_emb with {tablek.shape[0]} rows")
 
 
+# ------------------------------------------------------------------------------------ deferred reductions
+# A weight-gradient launch leaves per-block partial sums that a small second launch adds up.  Inside
+# `deferred_reductions()` that second launch is not issued: the job (kpgnn_reduce_job) waits in this list and the next
+# table-gradient call - which has a finishing launch of its own - takes it along (8 launches less per step at L = 8); what
+# is left when the block ends is run then.  The gradient tensors such a backward returns are NOT valid until the block
+# ends: only for callers that read gradients afterwards (torch.autograd.grad(...) inside the block, or .backward() into
+# parameters whose .grad is None) - never with gradient accumulation into existing .grad tensors or backward hooks.
+_pending_reduce = None        # None: off; list of (ReduceJob, tensors kept alive)
+
+
+class deferred_reductions:
+    def __enter__(self):
+        global _pending_reduce
+        self._outer = _pending_reduce
+        if _pending_reduce is None:
+            _pending_reduce = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_reduce
+        if self._outer is None:
+            jobs, _pending_reduce = _pending_reduce, None
+            if jobs and exc[0] is None:
+                flush_reductions(jobs)
+        return False
+
+
+def flush_reductions(jobs):
+    arr = (_lib.ReduceJob * len(jobs))(*[j for j, _ in jobs])
+    dev = jobs[0][1][0].device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().kpgnn_reduce_jobs(arr, len(jobs), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_reduce_jobs")
+
+
+def defer_reduce_job():
+    """A fresh job slot when reductions are being deferred (the caller hands ctypes.byref(job) to a launch with a `defer`
+    field, then calls queue_reduce_job), else None."""
+    return _lib.ReduceJob() if _pending_reduce is not None else None
+
+
+def queue_reduce_job(job, keep_alive):
+    _pending_reduce.append((job, keep_alive))
+
+
+def take_reduce_job():
+    """The oldest waiting job, or None: for a call whose finishing launch can take one along."""
+    if _pending_reduce:
+        return _pending_reduce.pop(0)
+    return None
+
+
 class DictPeripheral:
     """Dictionary form of the peripheral features: P[i,k,:] = table[uid[i,k], :].
 
@@ -442,6 +493,9 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
         eo = extra[0] if gdict_acc is None else gdict_acc
         assert eo.numel() == extra[0].numel()
         d.extra_out, d.extra_slab, d.extra_nslab, d.extra_elems = eo.data_ptr(), extra[1].data_ptr(), extra[2], extra[0].numel()
+    waiting = take_reduce_job()        # (an earlier launch's deferred reduction rides along with the finishing launch)
+    if waiting is not None:
+        d.pending = ctypes.cast(ctypes.pointer(waiting[0]), ctypes.c_void_p)
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -365,10 +365,16 @@ class FusedMLP(torch.autograd.Function):
         b.dw, b.db = dw0.data_ptr(), db[1].data_ptr()
         with torch.cuda.device(dev):
             if I == O:
+                from . import ops
                 nb = 2 * int(lib.kpgnn_wgrad_workspace_bytes(O, O))
                 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                 a.workspace, a.workspace_bytes = ws.data_ptr(), nb
+                job = ops.defer_reduce_job()          # (inside ops.deferred_reductions(): the reduce rides with a later launch)
+                if job is not None:
+                    a.defer = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
                 _lib.check(lib.kpgnn_linear_wgrad_pair(ctypes.byref(a), ctypes.byref(b), _stream(h)), "kpgnn_linear_wgrad_pair")
+                if job is not None:
+                    ops.queue_reduce_job(job, (ws, dw3, dw0, db))
             else:
                 for q in (a, b):
                     nb = int(lib.kpgnn_wgrad_workspace_bytes(q.O, q.I))

@@ -1491,3 +1491,53 @@ def test_flat_adam_equals_framework_adam(wd):
     _close(flat_p, ref, "param after 5 steps", rtol=1e-5, atol=1e-6)
     _close(opt.exp_avg, opt_ref.state[ref]["exp_avg"], "exp_avg", rtol=1e-5, atol=1e-7)
     _close(opt.exp_avg_sq, opt_ref.state[ref]["exp_avg_sq"], "exp_avg_sq", rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("batch", [24, 300])
+def test_deferred_reductions_give_the_same_bits(batch):
+    """ops.deferred_reductions(): the weight-gradient reduce of each layer's MLP (kpgnn_linear_wgrad_pair, desc.defer) is
+    added up by the next table-gradient call's finishing launch (kpgnn_table_grad_desc.pending) or, for what is left, by
+    kpgnn_reduce_jobs at the end of the block - same sums in the same order: every parameter gradient is bitwise the one of
+    the plain run (h = 32: a width the fused MLP covers; batch 300 has N >= 4096, the dict_grad + pending + theta finish)."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    K, L, H = 3, 4, 32
+    model = _small_body("KPGINPlus", "geometric", K, L, H).to(dev).train()
+    b = synthetic_zinc_batch(batch, seed0=7, K=K).to(dev)
+    b.build_csr()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads(deferred):
+        score = model(b)
+        loss = (score.squeeze() - b.y.squeeze()).abs().mean()
+        if deferred:
+            with ops.deferred_reductions():
+                g = torch.autograd.grad(loss, params, allow_unused=True)
+                assert ops._pending_reduce is not None
+            assert ops._pending_reduce is None
+        else:
+            g = torch.autograd.grad(loss, params, allow_unused=True)
+        torch.cuda.synchronize()
+        return g
+
+    took = []
+    real = ops.take_reduce_job
+
+    def spy():
+        r = real()
+        took.append(r is not None)
+        return r
+
+    ops.take_reduce_job = spy
+    try:
+        a = grads(True)
+    finally:
+        ops.take_reduce_job = real
+    assert any(took), "no finishing launch took a deferred job along"
+    bb = grads(False)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    for n, x, y in zip(names, a, bb):
+        assert (x is None) == (y is None), n
+        if x is not None:
+            assert torch.equal(x, y), (n, float((x - y).abs().max()))
