@@ -530,6 +530,7 @@ dict_tile_pack_kernel(const int32_t* __restrict__ uid, int64_t uid_stride, int N
 // to three independent jobs (block ranges one after the other) and a theta-gradient finish.
 struct SlabJob {
     const float* slab; int nslab; int nblocks; int acc;    // acc bit i: out[i] += instead of =
+    int lo;                                                 // a block covers 1 << lo outputs with 1024 >> lo slices of the slab rows
     int64_t elems;
     float* out[4]; int64_t n[3];                            // outputs [0, n0) -> out[0], [n0, n0+n1) -> out[1], ... rest -> out[3]
 };
@@ -550,25 +551,25 @@ slab_reduce_kernel(const SlabArgs a) {
     const float* __restrict__ slab = J.slab;
     const int nslab = J.nslab;
     const int64_t elems = J.elems;
-    float (*part)[17] = reinterpret_cast<float (*)[17]>(sm);      // [64][17]
-    const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int64_t e = (int64_t)blk * 16 + o;
+    // few slab rows (small batches): fewer slices and more outputs per block, instead of 64 slices of which most idle
+    const int lo = J.lo, outs = 1 << lo, nsl = 1024 >> lo, pitch = outs + 1;
+    const int o = threadIdx.x & (outs - 1), slice = threadIdx.x >> lo;
+    const int64_t e = (int64_t)blk * outs + o;
     float s = 0.f;
     if (e < elems) {
         int b = slice;
-        for (; b + 192 < nslab; b += 256) {
-            const float v0 = slab[(int64_t)b * elems + e], v1 = slab[(int64_t)(b + 64) * elems + e];
-            const float v2 = slab[(int64_t)(b + 128) * elems + e], v3 = slab[(int64_t)(b + 192) * elems + e];
+        for (; b + 3 * nsl < nslab; b += 4 * nsl) {
+            const float v0 = slab[(int64_t)b * elems + e], v1 = slab[(int64_t)(b + nsl) * elems + e];
+            const float v2 = slab[(int64_t)(b + 2 * nsl) * elems + e], v3 = slab[(int64_t)(b + 3 * nsl) * elems + e];
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; b < nslab; b += 64) s += slab[(int64_t)b * elems + e];
+        for (; b < nslab; b += nsl) s += slab[(int64_t)b * elems + e];
     }
-    part[slice][o] = s;
+    sm[slice * pitch + o] = s;
     __syncthreads();
     if (slice == 0 && e < elems) {
         float tot = 0.f;
-#pragma unroll
-        for (int q = 0; q < 64; ++q) tot += part[q][o];
+        for (int q = 0; q < nsl; ++q) tot += sm[q * pitch + o];
         int which = 3;
         int64_t off = e;
         if (off < J.n[0]) which = 0;
@@ -582,10 +583,17 @@ slab_reduce_kernel(const SlabArgs a) {
 
 SlabJob empty_job() {
     SlabJob j;
-    j.slab = nullptr; j.nslab = 0; j.nblocks = 0; j.acc = 0; j.elems = 0;
+    j.slab = nullptr; j.nslab = 0; j.nblocks = 0; j.acc = 0; j.elems = 0; j.lo = 4;
     for (int i = 0; i < 4; ++i) j.out[i] = nullptr;
     j.n[0] = j.n[1] = j.n[2] = 0;
     return j;
+}
+
+// slices for a slab of nslab rows: 64 (16 outputs per block) from 96 rows on, 16 (64 outputs) from 16 rows on, else 4 (256)
+void shape_job(SlabJob* j) {
+    j->lo = j->nslab >= 96 ? 4 : (j->nslab >= 16 ? 6 : 8);
+    const int64_t outs = (int64_t)1 << j->lo;
+    j->nblocks = (int)((j->elems + outs - 1) / outs);
 }
 
 int public_job(const kpgnn_reduce_job* r, SlabJob* j) {
@@ -598,9 +606,10 @@ int public_job(const kpgnn_reduce_job* r, SlabJob* j) {
     }
     KPGNN_REQUIRE(tot == r->elems && r->nslab >= 1, "reduce job: the outputs cover %lld of %lld elements (nslab %d)",
                   (long long)tot, (long long)r->elems, r->nslab);
-    j->slab = r->slab; j->nslab = r->nslab; j->elems = r->elems; j->nblocks = (int)((r->elems + 15) / 16);
+    j->slab = r->slab; j->nslab = r->nslab; j->elems = r->elems;
     for (int i = 0; i < 4; ++i) j->out[i] = r->out[i];
     for (int i = 0; i < 3; ++i) j->n[i] = r->n_out[i];
+    shape_job(j);
     return KPGNN_OK;
 }
 
@@ -632,7 +641,8 @@ int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_
     a.j[0] = empty_job();
     if (elems > 0) {
         SlabJob& j = a.j[0];
-        j.slab = slab; j.nslab = nslab; j.elems = elems; j.nblocks = (int)((elems + 15) / 16);
+        j.slab = slab; j.nslab = nslab; j.elems = elems;
+        shape_job(&j);
         j.out[0] = out0; j.out[1] = out1; j.out[2] = out2; j.out[3] = out3;
         j.n[0] = n0; j.n[1] = n1; j.n[2] = n2;
         j.acc = (acc_mask & 1) ? 4 : 0;           // bit 0 of acc_mask: the third output accumulates
@@ -640,7 +650,8 @@ int slab_reduce(const float* slab, int nslab, int64_t elems, float* out0, int64_
     a.j[1] = empty_job();
     if (elems_b > 0) {
         SlabJob& j = a.j[1];
-        j.slab = slab_b; j.nslab = nslab_b; j.elems = elems_b; j.nblocks = (int)((elems_b + 15) / 16);
+        j.slab = slab_b; j.nslab = nslab_b; j.elems = elems_b;
+        shape_job(&j);
         j.out[0] = out_b; j.n[0] = elems_b;
         j.acc = (acc_mask & 2) ? 1 : 0;
     }
