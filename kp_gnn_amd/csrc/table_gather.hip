@@ -90,6 +90,69 @@ tgs_kernel(const TgsParams p) {
     }
 }
 
+// ---- few rows (M * C <= kSmallPairs): the peripheral DICTIONARY of a batch has ~25 distinct (node, hop) feature tuples,
+// whatever the batch size.  The kernels above then run as ONE block that first copies a ~250 KB table into LDS (forward,
+// 15 us) or walks 25 x 13 LDS float adds as one serial chain (backward, 32 us + the slab reduce).  Here:
+//   forward  one block per row m; a thread owns a column and sums its C table rows straight from L2 (independent loads);
+//   backward "pull": one block per TABLE row r scans the M * C (row, component) pairs 64 at a time (ballot), and adds
+//            gout[m, :] for the pairs that address r, in (m, c) order - every table row is written once, by one block:
+//            no accumulator table, no slab, no second launch, bitwise reproducible.
+constexpr int kSmallPairs = 4096;
+constexpr int kSmallBlock = 128;
+
+__global__ void __launch_bounds__(kSmallBlock)
+tgs_small_fwd_kernel(const TgsParams p) {
+    const int64_t m = blockIdx.x;
+    const uint16_t* ix = p.idx + m * p.C;
+    for (int col = threadIdx.x; col < p.D; col += kSmallBlock) {
+        float acc = p.bias ? p.bias[col] : 0.f;
+        int c = 0;
+        for (; c + 3 < p.C; c += 4) {        // four rows in flight; added in component order
+            const float v0 = p.table[(int64_t)(p.col_offset[c] + (int)ix[c]) * p.D + col];
+            const float v1 = p.table[(int64_t)(p.col_offset[c + 1] + (int)ix[c + 1]) * p.D + col];
+            const float v2 = p.table[(int64_t)(p.col_offset[c + 2] + (int)ix[c + 2]) * p.D + col];
+            const float v3 = p.table[(int64_t)(p.col_offset[c + 3] + (int)ix[c + 3]) * p.D + col];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; c < p.C; ++c) acc += p.table[(int64_t)(p.col_offset[c] + (int)ix[c]) * p.D + col];
+        p.out[m * p.out_stride + col] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(kSmallBlock)
+tgs_small_bwd_kernel(const TgsParams p) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pairs = (int)p.M * p.C;
+    float acc[2] = {0.f, 0.f};               // columns tid and tid + 128 (D <= 256)
+    for (int p0 = 0; p0 < pairs; p0 += kWave) {
+        const int q = p0 + lane;
+        bool hit = false;
+        if (q < pairs) hit = p.col_offset[q % p.C] + (int)p.idx[q] == r;
+        unsigned long long mask = __ballot(hit);                // (every wave of the block computes the same mask)
+        while (mask) {
+            const int j = (int)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int64_t m = (p0 + j) / p.C;
+            const float* g = p.gout + m * p.gout_stride;
+            if ((int)threadIdx.x < p.D) acc[0] += g[threadIdx.x];
+            if ((int)threadIdx.x + kSmallBlock < p.D) acc[1] += g[threadIdx.x + kSmallBlock];
+        }
+    }
+    if ((int)threadIdx.x < p.D) p.gtable[(int64_t)r * p.D + threadIdx.x] = acc[0];
+    if ((int)threadIdx.x + kSmallBlock < p.D) p.gtable[(int64_t)r * p.D + threadIdx.x + kSmallBlock] = acc[1];
+}
+
+bool tgs_small(const kpgnn_tgs_desc* d) { return d->M * (int64_t)d->C <= kSmallPairs && d->D <= 2 * kSmallBlock; }
+
+TgsParams tgs_params(const kpgnn_tgs_desc* d) {
+    TgsParams p;
+    p.M = d->M; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = d->D; p.idx = d->idx; p.col_offset = d->col_offset;
+    p.table = d->table; p.bias = d->bias; p.out = d->out; p.out_stride = d->out_stride;
+    p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
+    return p;
+}
+
 // Backward: gtable[col_offset[c] + idx[m,c], :] += gout[m, :].  Block = NG groups of CW threads (CW = pow2 >= Ds); the
 // block's contiguous run of rows is cut into NG contiguous sub-runs, group g adds ITS rows in order into its private
 // accumulator table [R][CW] in LDS; then the groups are added in order and leave as slab row blockIdx.x.
@@ -302,6 +365,11 @@ int run_bwd(const kpgnn_tgs_desc* d, hipStream_t s) {
     KPGNN_REQUIRE(d->gtable != nullptr, "table_gather_sum_bwd: NULL gtable");
     if (d->M == 0) { KPGNN_HIP_TRY(hipMemsetAsync(d->gtable, 0, sizeof(float) * (size_t)d->R * d->D, s)); return KPGNN_OK; }
     KPGNN_REQUIRE(d->idx && d->col_offset && d->gout && d->gout_stride >= d->D, "table_gather_sum_bwd: NULL idx/col_offset/gout");
+    if (tgs_small(d)) {
+        hipLaunchKernelGGL(tgs_small_bwd_kernel, dim3((unsigned)d->R), dim3(kSmallBlock), 0, s, tgs_params(d));
+        KPGNN_LAUNCH_CHECK("tgs_small_bwd_kernel");
+        return KPGNN_OK;
+    }
     BwdPlan pl;
     if (!bwd_plan(d->M, d->D, d->R, &pl))
         return fail(KPGNN_ELIMIT, "table_gather_sum_bwd: R=%d rows do not fit LDS at any column split of D=%d", d->R, d->D);
@@ -327,6 +395,11 @@ int run(const kpgnn_tgs_desc* d, hipStream_t s) {
     KPGNN_REQUIRE(d->idx && d->col_offset, "table_gather_sum: NULL idx/col_offset");
     if (bwd) KPGNN_REQUIRE(d->gout && d->gtable && d->gout_stride >= d->D, "table_gather_sum_bwd: NULL gout/gtable");
     else KPGNN_REQUIRE(d->table && d->out && d->out_stride >= d->D, "table_gather_sum_fwd: NULL table/out");
+    if (!bwd && tgs_small(d)) {
+        hipLaunchKernelGGL(tgs_small_fwd_kernel, dim3((unsigned)d->M), dim3(kSmallBlock), 0, s, tgs_params(d));
+        KPGNN_LAUNCH_CHECK("tgs_small_fwd_kernel");
+        return KPGNN_OK;
+    }
     // column splits: the fewest such that the LDS slice fits and the slice width stays VEC-aligned
     const float* data = bwd ? d->gout : d->out;
     const int64_t stride = bwd ? d->gout_stride : d->out_stride;

@@ -483,16 +483,18 @@ def test_bf16_storage_body_vs_fp32_batch512():
 
 
 # ----------------------------------------------------------------------------- multi-table gather-sum
-@pytest.mark.parametrize("D,R_sizes", [(104, [5, 51] + [51] * 7), (13, [5, 51] + [51] * 7), (6, [3, 4]), (96, [6, 1001, 30])])
-def test_table_gather_sum_vs_torch(D, R_sizes):
-    """Peripheral feature build: fwd + table/bias grads vs plain embedding sums (LDS-staged, column-split)."""
+@pytest.mark.parametrize("D,R_sizes", [(104, [5, 51] + [51] * 7), (13, [5, 51] + [51] * 7), (6, [3, 4]), (96, [6, 1001, 30]),
+                                       (200, [7, 9])])
+@pytest.mark.parametrize("M", [777, 25, 1])
+def test_table_gather_sum_vs_torch(D, R_sizes, M):
+    """Peripheral feature build: fwd + table/bias grads vs plain embedding sums (LDS-staged, column-split; M = 25, 1: the
+    few-row kernels - a batch's peripheral dictionary - one block per row forward, one block per table row backward)."""
     from kp_gnn_amd.ops import table_gather_sum
     dev = _dev()
     g = torch.Generator().manual_seed(D)
     C = len(R_sizes) + 2  # the first two tables are used twice (type/count of several edge types)
     tab_of_col = [0, 1] + list(range(len(R_sizes)))
     starts = np.concatenate([[0], np.cumsum(R_sizes)])
-    M = 777
     idx = torch.stack([torch.randint(0, R_sizes[t], (M,), generator=g) for t in tab_of_col], 1)
     table = torch.randn(int(starts[-1]), D, generator=g)
     bias = torch.randn(D, generator=g)
