@@ -90,7 +90,7 @@ tgs_kernel(const TgsParams p) {
     }
 }
 
-// ---- few rows (M * C <= kSmallPairs): the peripheral DICTIONARY of a batch has ~25 distinct (node, hop) feature tuples,
+// ---- few rows (M <= kSmallRows, M * C <= kSmallPairs): the peripheral DICTIONARY of a batch has ~25 distinct (node, hop) feature tuples,
 // whatever the batch size.  The kernels above then run as ONE block that first copies a ~250 KB table into LDS (forward,
 // 15 us) or walks 25 x 13 LDS float adds as one serial chain (backward, 32 us + the slab reduce).  Here:
 //   forward  one block per row m; a thread owns a column and sums its C table rows straight from L2 (independent loads);
@@ -143,7 +143,12 @@ tgs_small_bwd_kernel(const TgsParams p) {
     if ((int)threadIdx.x + kSmallBlock < p.D) p.gtable[(int64_t)r * p.D + threadIdx.x + kSmallBlock] = acc[1];
 }
 
-bool tgs_small(const kpgnn_tgs_desc* d) { return d->M * (int64_t)d->C <= kSmallPairs && d->D <= 2 * kSmallBlock; }
+// (few ROWS, not just few pairs: a table row that most of 1,480 single-component rows address - the carbon row of a node-feature
+//  table - makes the pull kernel's block a chain of a thousand dependent loads: 51 us against the histogram kernel's 16)
+constexpr int kSmallRows = 256;
+bool tgs_small(const kpgnn_tgs_desc* d) {
+    return d->M <= kSmallRows && d->M * (int64_t)d->C <= kSmallPairs && d->D <= 2 * kSmallBlock;
+}
 
 TgsParams tgs_params(const kpgnn_tgs_desc* d) {
     TgsParams p;

@@ -26,6 +26,9 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
             self.combine = make_combine(combine, K, output_size)  # raises for "independent" like the reference
         else:
             self.combine = torch.squeeze
+            # (one hop: the combine is the identity; on the GPU the layer asks for the fused epilogue with theta = 1, so that its
+            #  backward is the fused combine + table-gradient kernel like every other layer's: 3 launches instead of 6)
+            self.register_buffer("_theta_one", torch.ones(1, input_size), persistent=False)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -56,6 +59,9 @@ class KPGINPlusConv(KHopMessagePassing, EdgeCodeTables):
         if isinstance(self.combine, GeometricCombine):
             h = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
                                theta=self.combine.alphas, xbias=xbias, share_slot_grads=_history)   # N,H
+        elif self.K == 1 and k_act == 1 and self._theta_one.is_cuda and n > 1:
+            h = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
+                               theta=self._theta_one, xbias=xbias, share_slot_grads=_history)       # N,H (= squeeze of N,1,H)
         else:
             xn = khop_aggregate(x, csr, k_act, MODE_GINPLUS, table0=t0, tablek=tk, periph=peripheral_attr,
                                 xbias=xbias, share_slot_grads=_history)                       # N,k,H

@@ -581,7 +581,9 @@ class KHopAggregate(torch.autograd.Function):
             # bf16 storage (set_storage_dtype): only the configuration the bf16 kernels exist for - the fused KP-GIN+
             # epilogue with a dictionary P and code tables; everything else stays fp32
             bf16 = (_STORAGE is torch.bfloat16 and mode == MODE_GINPLUS and theta is not None and ptab is not None
-                    and periph is None and table0 is not None and xs[0].shape[1] % 8 == 0 and eps is None)
+                    and periph is None and table0 is not None and xs[0].shape[1] % 8 == 0 and eps is None and k_act > 1)
+            # (k_act > 1: the single-hop first layer reads the raw input embedding once - nothing to save, and its rounding
+            #  is what the ill-conditioned gradients of the input encoders' scalar gates feel first)
             xs = [bf16_shadow(t) if bf16 else t.float() for t in xs]
             # the kernel reads every hop slot with ONE row stride (x_sn): row-strided slots (column slices of the bodies'
             # jumping-knowledge buffer) are read where they are; only mixed layouts are copied
