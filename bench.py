@@ -116,21 +116,24 @@ def fwd_bwd(args, model, batch, flat_grad):
 
 def train_step(args, model, batch, opt, flat_grad, world, graph=None):
     """One step.  With `graph` (a captured hipGraph of fwd+bwd on this batch's static tensors) the launches of
-    forward+backward replay as one graph launch; the gradient all-reduce and the fused Adam step stay eager (a
-    collective inside a captured graph is the one thing that cannot be rehearsed on 1 GPU)."""
+    forward+backward replay as one graph launch; the gradient all-reduce and the Adam step stay eager (a collective inside a
+    captured graph is the one thing that cannot be rehearsed on 1 GPU).  --adam-in-graph (1 GPU) makes the Adam launch - its
+    step number on the device - the graph's last node instead."""
+    stepped = False
     if graph is not None:
         graph[0].replay()
-        out = graph[1]
+        out, stepped = graph[1], graph[2]
     else:
         out = fwd_bwd(args, model, batch, flat_grad)
-    if args.train:
+    if args.train and not stepped:
         dp.allreduce_mean(flat_grad, world)
         opt.step()
     return out
 
 
-def capture_graphs(args, model, batches, flat_grad):
-    """hipGraph capture of fwd+bwd, one graph per pre-staged batch (shapes differ between batches)."""
+def capture_graphs(args, model, batches, flat_grad, opt=None):
+    """hipGraph capture of fwd+bwd (+ the optimiser step when `opt` is given: single process, device-side step number), one
+    graph per pre-staged batch (shapes differ between batches)."""
     graphs = []
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -147,8 +150,10 @@ def capture_graphs(args, model, batches, flat_grad):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
             out = fwd_bwd(args, model, b, flat_grad)
+            if opt is not None:
+                opt.step()
         pool = g.pool()
-        graphs.append((g, out))
+        graphs.append((g, out, opt is not None))
     return graphs
 
 
@@ -263,6 +268,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--adam-in-graph", action="store_true",
+                    help="1 GPU: capture the optimiser step (device-side step number) in the graph; measured 20 us SLOWER per step "
+                         "than the eager launch behind the replay (its 480 blocks take a same-address ticket each)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -331,7 +339,8 @@ def main():
         flat_grad = dp.flatten_grads(model)
         flat_param = dp.flatten_params(model)     # parameters and gradients: one flat bucket each (same order)
         flat_param.grad = flat_grad
-        opt = dp.FlatAdam(flat_param, flat_grad, lr=1e-3)    # elementwise: identical to per-parameter Adam (train_ZINC.py:244)
+        # elementwise: identical to per-parameter Adam (train_ZINC.py:244)
+        opt = dp.FlatAdam(flat_param, flat_grad, lr=1e-3, device_step=(world == 1 and not args.no_graph and args.adam_in_graph))
 
     def barrier():
         torch.cuda.synchronize()
@@ -345,7 +354,7 @@ def main():
     graphs = None
     if not args.no_graph:
         # (a capture failure is an error, not a silent downgrade to eager launches: --no-graph asks for those)
-        graphs = capture_graphs(args, model, batches, flat_grad)
+        graphs = capture_graphs(args, model, batches, flat_grad, opt if (args.train and world == 1 and args.adam_in_graph) else None)
         for i in range(len(batches)):  # one replayed step per graph before timing
             train_step(args, model, batches[i], opt, flat_grad, world, graphs[i])
         torch.cuda.synchronize()

@@ -102,6 +102,12 @@ int kpgnn_regression_loss(const float* score, const float* y, int64_t n, int32_t
 int kpgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                     double lr, double beta1, double beta2, double eps, double weight_decay, kpgnn_stream_t stream);
 
+/* The same step with the step number kept on the device: state = int64[2] {steps taken so far, 0}, both zero before the
+ * first call; the launch reads state[0], steps with t = state[0] + 1 and leaves state[0] = t.  Its arguments never change,
+ * so it can be captured in a hipGraph together with the forward and backward passes (one process, no all-reduce between). */
+int kpgnn_adam_step_device(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t* state,
+                           double lr, double beta1, double beta2, double eps, double weight_decay, kpgnn_stream_t stream);
+
 /* count contiguous fp32 tensors copied device-to-device in ceil(count / 192) launches: dst[i][0..numel[i]) = src[i][..].  The
  * pointer tables are HOST arrays read at call time and passed to the kernel by value (capturable: a hipGraph node keeps
  * them).  Used to move a step's parameter gradients into their views of the flat all-reduce bucket (train_ZINC.py:34-36

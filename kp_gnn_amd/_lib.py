@@ -212,6 +212,8 @@ SIGNATURES = {
     "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_double, c_vp]),
     "kpgnn_reduce_jobs": (ctypes.c_int, [c_vp, c_i32, c_vp]),
+    "kpgnn_adam_step_device": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp]),
     "kpgnn_multi_copy": (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_dict_tile_pack": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_combine_bwd_workspace_bytes": (ctypes.c_size_t, [c_i32] * 3),

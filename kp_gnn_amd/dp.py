@@ -79,7 +79,7 @@ class FlatAdam:
     flat gradient bucket of flatten_grads: ONE elementwise launch per step (kpgnn_adam_step) instead of the framework's
     multi-tensor kernel over 65,536-element chunks (8 blocks, 42 us for 0.5 M parameters) plus its step-counter launch."""
 
-    def __init__(self, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, device_step=False):
         assert flat_param.is_cuda and flat_param.dtype == torch.float32 and flat_param.is_contiguous()
         assert flat_grad.shape == flat_param.shape and flat_grad.dtype == torch.float32 and flat_grad.is_contiguous()
         self.param, self.grad = flat_param, flat_grad
@@ -87,14 +87,24 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(flat_param.data)
         self.exp_avg_sq = torch.zeros_like(flat_param.data)
         self.steps = 0
+        # device_step: the step number lives in device memory (kpgnn_adam_step_device) - the launch can then be captured in
+        # a hipGraph with the passes it follows; `steps` is not maintained on the host in that mode
+        self.state = torch.zeros(2, dtype=torch.int64, device=flat_param.device) if device_step else None
 
     def zero_grad(self):
         self.grad.zero_()
 
     def step(self):
         from . import _lib
-        self.steps += 1
         dev = self.param.device
+        if self.state is not None:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().kpgnn_adam_step_device(
+                    self.param.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                    self.param.numel(), self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                    self.weight_decay, torch.cuda.current_stream(dev).cuda_stream), "kpgnn_adam_step_device")
+            return
+        self.steps += 1
         with torch.cuda.device(dev):
             _lib.check(_lib.load().kpgnn_adam_step(
                 self.param.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),

@@ -1472,9 +1472,11 @@ def test_regression_loss_vs_framework_ops(n, kind):
 
 
 @pytest.mark.parametrize("wd", [0.0, 0.01])
-def test_flat_adam_equals_framework_adam(wd):
-    """dp.FlatAdam (kpgnn_adam_step) on a flat bucket against torch.optim.Adam on the same numbers, five steps with fresh
-    gradients (n not a multiple of 4: the scalar tail)."""
+@pytest.mark.parametrize("device_step", [False, True])
+def test_flat_adam_equals_framework_adam(wd, device_step):
+    """dp.FlatAdam (kpgnn_adam_step / kpgnn_adam_step_device) on a flat bucket against torch.optim.Adam on the same numbers,
+    five steps with fresh gradients (n not a multiple of 4: the scalar tail); with the step number on the device the last
+    three steps are replays of ONE captured launch."""
     from kp_gnn_amd import dp
     dev = _dev()
     g = torch.Generator().manual_seed(3)
@@ -1483,13 +1485,25 @@ def test_flat_adam_equals_framework_adam(wd):
     ref = torch.nn.Parameter(p0.clone())
     opt_ref = torch.optim.Adam([ref], lr=1e-2, weight_decay=wd)
     flat_p, flat_g = torch.nn.Parameter(p0.clone().to(dev)), torch.zeros(n, device=dev)
-    opt = dp.FlatAdam(flat_p, flat_g, lr=1e-2, weight_decay=wd)
-    for _ in range(5):
+    opt = dp.FlatAdam(flat_p, flat_g, lr=1e-2, weight_decay=wd, device_step=device_step)
+    graph = None
+    for it in range(5):
         grad = torch.randn(n, generator=g) * torch.rand(n, generator=g) ** 4
         ref.grad = grad.clone()
         flat_g.copy_(grad.to(dev))
         opt_ref.step()
-        opt.step()
+        if device_step and it == 2:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                opt.step()                       # (capture does not run it)
+        if graph is not None:
+            graph.replay()
+        else:
+            opt.step()
+    if device_step:
+        torch.cuda.synchronize()
+        assert opt.state.tolist() == [5, 0]
     _close(flat_p, ref, "param after 5 steps", rtol=1e-5, atol=1e-6)
     _close(opt.exp_avg, opt_ref.state[ref]["exp_avg"], "exp_avg", rtol=1e-5, atol=1e-7)
     _close(opt.exp_avg_sq, opt_ref.state[ref]["exp_avg_sq"], "exp_avg_sq", rtol=1e-5, atol=1e-9)
