@@ -56,31 +56,62 @@ __device__ __forceinline__ void wgrad_problem(const WgParams p, float* lds) {
             tm[t] = ok ? p.xm[i] : 0.f; ts[t] = ok ? p.xi[i] : 0.f; tg[t] = ok ? p.xg[i] : 0.f; tb[t] = ok ? p.xb[i] : 0.f;
         }
     }
-    // rows of this block: pairs (r, r+1); block b takes pairs b, b+grid, ...
+    // rows of this block: pairs (r, r+1); row group vb takes pairs vb, vb + vgrid, ...; UN pairs make a batch.
+    // Full batches (all but the last) load WITHOUT predicates from a wave-uniform row pointer plus a per-lane 32-bit
+    // offset fixed for the whole problem: lanes of padded columns (o >= O, i >= I) are pointed at the last valid column -
+    // what they accumulate lands in output rows / columns that are never stored.  (Per-load 64-bit address arithmetic and
+    // the row / column selects were a third of the loop's issue slots next to the 4 MFMAs per pair.)
     const int64_t pairs = (p.N + 1) / 2;
     constexpr int UN = 4;
+    const int dyo = kk * (int)p.dys + (o_ok ? o : p.O - 1);
+    int xo[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) xo[t] = kk * (int)p.xs + min(t * 32 + c, p.I - 1);
     for (int64_t pr = vb; pr < pairs; pr += vgrid * UN) {
         float a[UN], b[UN][TI];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t r = 2 * (pr + (int64_t)u * vgrid) + kk;
-            const bool r_ok = r < p.N;
-            a[u] = (r_ok && o_ok) ? p.dy[r * p.dys + o] : 0.f;
-#pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                const int i = t * 32 + c;
-                b[u][t] = (r_ok && i < p.I) ? p.x[r * p.xs + i] : 0.f;
-            }
-        }
-        if (tr) {
+        const bool full = 2 * (pr + (int64_t)(UN - 1) * vgrid) + 1 < p.N;      // wave-uniform
+        if (full) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const bool r_ok = 2 * (pr + (int64_t)u * vgrid) + kk < p.N;
+                const int64_t r0 = 2 * (pr + (int64_t)u * vgrid);
+                const float* dyr = p.dy + r0 * p.dys;
+                const float* xr = p.x + r0 * p.xs;
+                a[u] = dyr[dyo];
+#pragma unroll
+                for (int t = 0; t < TI; ++t) b[u][t] = xr[xo[t]];
+            }
+            if (tr) {
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int t = 0; t < TI; ++t) {
+                        float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
+                        if (p.xrelu) v = fmaxf(v, 0.f);
+                        b[u][t] = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t r = 2 * (pr + (int64_t)u * vgrid) + kk;
+                const bool r_ok = r < p.N;
+                a[u] = (r_ok && o_ok) ? p.dy[r * p.dys + o] : 0.f;
 #pragma unroll
                 for (int t = 0; t < TI; ++t) {
-                    float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
-                    if (p.xrelu) v = fmaxf(v, 0.f);
-                    b[u][t] = (r_ok && t * 32 + c < p.I) ? v : 0.f;
+                    const int i = t * 32 + c;
+                    b[u][t] = (r_ok && i < p.I) ? p.x[r * p.xs + i] : 0.f;
+                }
+            }
+            if (tr) {
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const bool r_ok = 2 * (pr + (int64_t)u * vgrid) + kk < p.N;
+#pragma unroll
+                    for (int t = 0; t < TI; ++t) {
+                        float v = fmaf((b[u][t] - tm[t]) * ts[t], tg[t], tb[t]);
+                        if (p.xrelu) v = fmaxf(v, 0.f);
+                        b[u][t] = (r_ok && t * 32 + c < p.I) ? v : 0.f;
+                    }
                 }
             }
         }
