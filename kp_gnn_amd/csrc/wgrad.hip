@@ -331,7 +331,7 @@ linear_wide_kernel(const LinParams p) {
         const int64_t r0 = tile * ROWS;
         const float* b0 = xl + c * pitch + kk;
 #pragma unroll 1
-        for (int chunk = 0; chunk < O; chunk += 128) {
+        for (int chunk = (int)blockIdx.y * 128; chunk < O; chunk += 128 * (int)gridDim.y) {   // (few row tiles: chunks over blockIdx.y)
             // the operand reads below do not depend on the chunk: without this the compiler hoists all of them out of
             // the loop and spills ~500 registers
             int z = 0;
@@ -422,9 +422,14 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const int64_t grid = (m == 1 ? slots * 2 : slots) < tiles ? (m == 1 ? slots * 2 : slots) : tiles;
     dim3 blk(256);
     const int ks = (d->I + 1) / 2;
+    // a small batch has fewer row tiles than the chip has block slots: the output chunks of a tile are then spread over
+    // blockIdx.y instead of walked one after the other (batch 64, [1.5k,104] x [104,936]: one block chain of 8 chunks, 31 us)
+    const int64_t nchunks = (d->O + 127) / 128;
+    int64_t gy = tiles < slots ? (slots + tiles - 1) / tiles : 1;
+    if (gy > nchunks) gy = nchunks;
 #define KP_LIN2(KSV, MV) do { \
         KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)linear_wide_kernel<KSV, MV>, lds)); \
-        hipLaunchKernelGGL((linear_wide_kernel<KSV, MV>), dim3((unsigned)grid), blk, lds, s, p); } while (0)
+        hipLaunchKernelGGL((linear_wide_kernel<KSV, MV>), dim3((unsigned)grid, (unsigned)gy), blk, lds, s, p); } while (0)
 #define KP_LIN(KSV) do { if (m == 1) KP_LIN2(KSV, 1); else if (m == 2) KP_LIN2(KSV, 2); else KP_LIN2(KSV, 3); } while (0)
     if (ks == 16) KP_LIN(16);
     else if (ks == 32) KP_LIN(32);
