@@ -1,5 +1,5 @@
 # Round-2 measurements, one gpurun call:  bash scripts/measure_round.sh   -> gpurun_out/r02fin/ (copy what is judged to profiles/r02/)
-cd $GRAFT_REPO_ROOT && R=$GRAFT_REPO_ROOT/gpurun_out/r02fin && mkdir -p $R
+cd $GRAFT_REPO_ROOT && R=$GRAFT_REPO_ROOT/gpurun_out/r02fin && rm -rf $R && mkdir -p $R
 B="python bench.py"
 PB="python3 $GRAFT_REPO_ROOT/bench.py"
 run() { name=$1; shift; timeout -k 10 400 $B "$@" > $R/$name.json 2> $R/$name.log; echo "$name rc=$?"; }
