@@ -425,6 +425,17 @@ typedef struct kpgnn_bn_desc {
     int32_t stats_ready;                    /* 1: stat_slot already holds sum x / sum x^2 (no stats pass) */
     double* out_slot;                       /* optional (zeroed) slot receiving the statistics of z, or NULL */
     int64_t* num_batches_tracked;           /* device scalar, += 1 per call, or NULL (nn.BatchNorm1d's counter) */
+    /* Optional SECOND BatchNorm applied to the result by the same call (the layers' MLP-tail norm followed by the bodies'
+     * per-layer norm, KPGINplus.py:25-30 + models/GNNs.py:440-441):
+     *   z = bn_outer([relu](bn(x))) + residual
+     * with stats_ready = 1 and out_slot a zeroed slot (it receives the statistics of the intermediate).  Two launches: a
+     * statistics-only pass over x and one apply pass - the intermediate is never written (one [N,C] store and load less
+     * than two kpgnn_bn_fwd calls).  outer_mean / outer_invstd [C] are outputs like mean / invstd; the outer running
+     * statistics are updated like the inner ones. */
+    const float* outer_gamma; const float* outer_beta;   /* NULL: no second norm */
+    float outer_eps, outer_momentum;
+    float* outer_running_mean; float* outer_running_var; int64_t* outer_num_batches_tracked;
+    float* outer_mean; float* outer_invstd;
 } kpgnn_bn_desc;
 
 typedef struct kpgnn_bn_bwd_desc {

@@ -91,6 +91,9 @@ class BnDesc(ctypes.Structure):
         ("running_mean", c_vp), ("running_var", c_vp), ("mean", c_vp), ("invstd", c_vp),
         ("z", c_vp), ("z_stride", c_i64), ("residual", c_vp), ("r_stride", c_i64),
         ("stat_slot", c_vp), ("stats_ready", c_i32), ("out_slot", c_vp), ("num_batches_tracked", c_vp),
+        ("outer_gamma", c_vp), ("outer_beta", c_vp), ("outer_eps", ctypes.c_float), ("outer_momentum", ctypes.c_float),
+        ("outer_running_mean", c_vp), ("outer_running_var", c_vp), ("outer_num_batches_tracked", c_vp),
+        ("outer_mean", c_vp), ("outer_invstd", c_vp),
     ]
 
 

@@ -45,6 +45,8 @@ struct BnParams {
     float* dgamma; float* dbeta;
     float* racc; int64_t racs;         // bwd apply: racc[r,:] += dz[r,:] (the residual branch's gradient, accumulated in place)
     const float* o_mean; const float* o_invstd;   // stacked reduce: the OUTER BatchNorm's statistics
+    // stacked forward: the outer norm
+    const float* og; const float* ob; float oeps, omom; float* ormean; float* orvar; int64_t* onbt; float* omean; float* oinvstd;
 };
 
 __device__ __forceinline__ double slot_sum(const double* slot, int C, int which, int c) {
@@ -217,6 +219,110 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p)
     block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
 }
 
+// Stacked forward, pass 1: the statistics (sum z, sum z^2) of z = [relu](bn(x)) into out_slot WITHOUT writing z; every block
+// finishes bn's mean / invstd from in_slot, block 0 publishes them and updates the running statistics.
+template <int VEC, int G>
+__global__ void __launch_bounds__(kBlock) bn_act_stats_kernel(const BnParams p) {
+    __shared__ float cm[2][G * VEC];
+    const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
+    const bool col_ok = c0 < p.C;
+    for (int c = threadIdx.x; c < p.C; c += kBlock) {
+        const double inv_n = 1.0 / (double)p.N;
+        const double m1 = slot_sum(p.in_slot, p.C, 0, c) * inv_n;
+        double var = slot_sum(p.in_slot, p.C, 1, c) * inv_n - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m1, istd = (float)(1.0 / sqrt(var + (double)p.eps));
+        cm[0][c] = mean; cm[1][c] = istd;
+        if (blockIdx.x == 0) {
+            p.mean[c] = mean; p.invstd[c] = istd;
+            if (p.rmean) {
+                const double unb = p.N > 1 ? var * (double)p.N / (double)(p.N - 1) : var;
+                p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mean;
+                p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.nbt) *p.nbt += 1;
+    __syncthreads();
+    double a[VEC], b[VEC];
+    for (int q = 0; q < VEC; ++q) { a[q] = 0.0; b[q] = 0.0; }
+    if (col_ok) {
+        float mean[VEC], istd[VEC], g[VEC], bt[VEC];
+        for (int q = 0; q < VEC; ++q) { mean[q] = cm[0][c0 + q]; istd[q] = cm[1][c0 + q]; }
+        ldv<VEC>(p.gamma + c0, g);
+        ldv<VEC>(p.beta + c0, bt);
+        const int64_t step = (int64_t)gridDim.x * (kBlock / G);
+        int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl;
+        auto one = [&](const float (&v)[VEC]) {
+            for (int q = 0; q < VEC; ++q) {
+                float z = fmaf((v[q] - mean[q]) * istd[q], g[q], bt[q]);
+                if (p.relu) z = fmaxf(z, 0.f);
+                a[q] += z; b[q] = fma((double)z, (double)z, b[q]);
+            }
+        };
+        for (; r + 3 * step < p.N; r += 4 * step) {
+            float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+            ldv<VEC>(p.x + r * p.xs + c0, v0);
+            ldv<VEC>(p.x + (r + step) * p.xs + c0, v1);
+            ldv<VEC>(p.x + (r + 2 * step) * p.xs + c0, v2);
+            ldv<VEC>(p.x + (r + 3 * step) * p.xs + c0, v3);
+            one(v0); one(v1); one(v2); one(v3);
+        }
+        for (; r < p.N; r += step) {
+            float v[VEC];
+            ldv<VEC>(p.x + r * p.xs + c0, v);
+            one(v);
+        }
+    }
+    block_to_slot<VEC, G>(p.out_slot, p.C, a, b, c0, col_ok);
+}
+
+// Stacked forward, pass 2: out = bn_o([relu](bn(x))) + residual; bn's mean / invstd are read from where pass 1 published
+// them, bn_o's are finished from in_slot (the statistics of the intermediate) by every block.
+template <int VEC, int G>
+__global__ void __launch_bounds__(kBlock) bn_apply2_kernel(const BnParams p) {
+    __shared__ float cm[2][G * VEC];
+    const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
+    for (int c = threadIdx.x; c < p.C; c += kBlock) {
+        const double inv_n = 1.0 / (double)p.N;
+        const double m1 = slot_sum(p.in_slot, p.C, 0, c) * inv_n;
+        double var = slot_sum(p.in_slot, p.C, 1, c) * inv_n - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m1, istd = (float)(1.0 / sqrt(var + (double)p.oeps));
+        cm[0][c] = mean; cm[1][c] = istd;
+        if (blockIdx.x == 0) {
+            p.omean[c] = mean; p.oinvstd[c] = istd;
+            if (p.ormean) {
+                const double unb = p.N > 1 ? var * (double)p.N / (double)(p.N - 1) : var;
+                p.ormean[c] = (1.f - p.omom) * p.ormean[c] + p.omom * mean;
+                p.orvar[c] = (1.f - p.omom) * p.orvar[c] + p.omom * (float)unb;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.onbt) *p.onbt += 1;
+    __syncthreads();
+    if (c0 >= p.C) return;
+    float mean[VEC], istd[VEC], g[VEC], bt[VEC], om[VEC], oi[VEC], og[VEC], ob[VEC];
+    ldv<VEC>(p.mean + c0, mean); ldv<VEC>(p.invstd + c0, istd); ldv<VEC>(p.gamma + c0, g); ldv<VEC>(p.beta + c0, bt);
+    ldv<VEC>(p.og + c0, og); ldv<VEC>(p.ob + c0, ob);
+    for (int q = 0; q < VEC; ++q) { om[q] = cm[0][c0 + q]; oi[q] = cm[1][c0 + q]; }
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / G) + rl; r < p.N; r += (int64_t)gridDim.x * (kBlock / G)) {
+        float v[VEC], o[VEC];
+        ldv<VEC>(p.x + r * p.xs + c0, v);
+        for (int q = 0; q < VEC; ++q) {
+            float z = fmaf((v[q] - mean[q]) * istd[q], g[q], bt[q]);
+            if (p.relu) z = fmaxf(z, 0.f);
+            o[q] = fmaf((z - om[q]) * oi[q], og[q], ob[q]);
+        }
+        if (p.res) {
+            float rr[VEC];
+            ldv<VEC>(p.res + r * p.rs + c0, rr);
+            for (int q = 0; q < VEC; ++q) o[q] += rr[q];
+        }
+        stv<VEC>(p.z + r * p.zs + c0, o);
+    }
+}
+
 // Stacked backward reduce: y -> z = [relu](bn_in(y)) -> h = bn_out(z) (+ residual), incoming gradient dh.  ONE pass over
 // (dh, y) leaves the eight column sums from which the consumer (lin_fused.h, PRO 3) finishes BOTH BatchNorms' backward
 // coefficients - the outer one's (sum dh, sum dh*xo) directly, the inner one's (sum dzm, sum dzm*xi with
@@ -371,6 +477,28 @@ extern "C" int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream) {
     p.mean = d->mean; p.invstd = d->invstd; p.z = d->z; p.zs = d->z_stride; p.res = d->residual; p.rs = d->r_stride;
     p.nbt = d->num_batches_tracked;
     hipStream_t s = (hipStream_t)stream;
+    if (d->outer_gamma) {
+        KPGNN_REQUIRE(d->stats_ready && d->out_slot && d->outer_beta && d->outer_mean && d->outer_invstd,
+                      "bn_fwd(stacked): needs stats_ready, out_slot, outer_beta, outer_mean, outer_invstd");
+        KPGNN_REQUIRE(!d->outer_running_mean == !d->outer_running_var, "bn_fwd(stacked): outer running statistics come in pairs");
+        {   // the outer parameters join the alignment that decides the vector width
+            int v2, g2;
+            rc = bn_shape(d->C, {d->x, d->z, d->gamma, d->beta, d->residual, d->outer_gamma, d->outer_beta, d->mean, d->invstd},
+                          {d->x_stride, d->z_stride, d->residual ? d->r_stride : 0}, &v2, &g2);
+            if (rc != KPGNN_OK) return rc;
+            vec = v2; g = g2;
+        }
+        p.in_slot = d->stat_slot; p.out_slot = d->out_slot;
+        const int nstat = stream_grid(d->N, g, kProducerBlocks);
+        KP_BN_SWITCH(bn_act_stats_kernel, nstat);
+        p.in_slot = d->out_slot; p.out_slot = nullptr;
+        p.og = d->outer_gamma; p.ob = d->outer_beta; p.oeps = d->outer_eps; p.omom = d->outer_momentum;
+        p.ormean = d->outer_running_mean; p.orvar = d->outer_running_var; p.onbt = d->outer_num_batches_tracked;
+        p.omean = d->outer_mean; p.oinvstd = d->outer_invstd;
+        const int napply = stream_grid(d->N, g, device_facts().cu_count * 8);
+        KP_BN_SWITCH(bn_apply2_kernel, napply);
+        return KPGNN_OK;
+    }
     if (!d->stats_ready) {
         p.out_slot = d->stat_slot;
         const int nstat = stream_grid(d->N, g, kProducerBlocks);

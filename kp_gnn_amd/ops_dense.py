@@ -271,7 +271,6 @@ class FusedMLP(torch.autograd.Function):
             out_slot = take_stat_slot(O, dev)
         y1 = torch.empty((N, O), dtype=torch.float32, device=dev)
         y2 = torch.empty((N, O), dtype=torch.float32, device=dev)
-        z = torch.empty((N, O), dtype=torch.float32, device=dev)
         st = torch.empty((6, O), dtype=torch.float32, device=dev)      # mean1, invstd1, mean2, invstd2, meanO, invstdO
         _lin_bn(lib, dev, N=N, O=O, I=I, x=h, w=w0c, bias=b0, y=y1, pro=0, epi=1, out_slot=slot1)
         track1 = bn1.track_running_stats
@@ -285,29 +284,27 @@ class FusedMLP(torch.autograd.Function):
         if bn2.track_running_stats:
             d.running_mean, d.running_var = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
             d.num_batches_tracked = bn2.num_batches_tracked.data_ptr()
-        d.mean, d.invstd, d.z, d.z_stride = st[2].data_ptr(), st[3].data_ptr(), z.data_ptr(), O
+        out = torch.empty((N, O), dtype=torch.float32, device=dev)
+        d.mean, d.invstd, d.z, d.z_stride = st[2].data_ptr(), st[3].data_ptr(), out.data_ptr(), O
         d.stat_slot, d.stats_ready, d.out_slot = slot2.data_ptr(), 1, _ptr(out_slot)
-        with torch.cuda.device(dev):
-            _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_fwd")
-        out = z
         ctx.outer, ctx.has_res, ctx.res_cell = outer, False, None
         if outer:
-            out = torch.empty((N, O), dtype=torch.float32, device=dev)
-            e = _lib.BnDesc()
-            e.N, e.C, e.relu, e.eps, e.momentum = N, O, 0, float(bnO.eps), float(bnO.momentum)
-            e.x, e.x_stride, e.gamma, e.beta = z.data_ptr(), O, gO.data_ptr(), beO.data_ptr()
+            # the body's norm (+ residual) by the same call: a statistics-only pass over y2, then one apply pass for both norms;
+            # z = relu(bn2(y2)) is never written (backward recomputes it from y2 as well)
+            d.outer_gamma, d.outer_beta = gO.data_ptr(), beO.data_ptr()
+            d.outer_eps, d.outer_momentum = float(bnO.eps), float(bnO.momentum)
             if bnO.track_running_stats:
-                e.running_mean, e.running_var = bnO.running_mean.data_ptr(), bnO.running_var.data_ptr()
-                e.num_batches_tracked = bnO.num_batches_tracked.data_ptr()
-            e.mean, e.invstd, e.z, e.z_stride = st[4].data_ptr(), st[5].data_ptr(), out.data_ptr(), O
+                d.outer_running_mean, d.outer_running_var = bnO.running_mean.data_ptr(), bnO.running_var.data_ptr()
+                d.outer_num_batches_tracked = bnO.num_batches_tracked.data_ptr()
+            d.outer_mean, d.outer_invstd = st[4].data_ptr(), st[5].data_ptr()
             if residual is not None:
                 residual = residual if residual.stride(-1) == 1 else residual.contiguous()
-                e.residual, e.r_stride = residual.data_ptr(), residual.stride(0)
+                d.residual, d.r_stride = residual.data_ptr(), residual.stride(0)
                 ctx.has_res = True
                 ctx.res_cell = getattr(residual, "_kp_slot_cell", None)
-            e.stat_slot, e.stats_ready = out_slot.data_ptr(), 1
-            with torch.cuda.device(dev):
-                _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(e), _stream(h)), "kpgnn_bn_fwd")
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_bn_fwd(ctypes.byref(d), _stream(h)), "kpgnn_bn_fwd")
+        if outer:
             ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st, gO)
         else:
             ctx.save_for_backward(h, w0c, w3c, g1, be1, g2, be2, y1, y2, st)
