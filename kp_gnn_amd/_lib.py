@@ -67,7 +67,7 @@ class DictGradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i32), ("K", c_i32), ("D", c_i32), ("n_dict", c_i32),
         ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp), ("gdict", c_vp),
-        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("defer_reduce", c_i32),
+        ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("defer_reduce", c_i32), ("dominant", c_vp),
     ]
 
 

@@ -175,7 +175,11 @@ class DictPeripheral:
     def __getitem__(self, idx):
         if (isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], slice)
                 and idx[1].start in (None, 0) and idx[1].step in (None, 1)):
-            return DictPeripheral(self.table, self.uid[:, idx[1]])
+            v = self.uid[:, idx[1]]
+            dom = getattr(self.uid, "_kp_dom", None)
+            if dom is not None:                      # (per-hop hint for the dictionary gradient: follows the hop prefix)
+                v._kp_dom = dom[idx[1]]
+            return DictPeripheral(self.table, v)
         return self.dense()[idx]
 
     def dense(self):
@@ -353,6 +357,9 @@ def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     d = _lib.DictGradDesc()
     d.N, d.K, d.D, d.n_dict = N, K, D, n_dict
     d.uid, d.uid_stride, d.theta, d.gh = uid.data_ptr(), uid.stride(0), theta.data_ptr(), gh.data_ptr()
+    dom = getattr(uid, "_kp_dom", None)          # [K] int32: the designated (most frequent) id per hop, if the caller has it
+    if dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == dev:
+        d.dominant = dom.data_ptr()
     gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
     d.gdict, d.workspace, d.workspace_bytes = gd.data_ptr(), ws.data_ptr(), int(ws_bytes)

@@ -991,6 +991,14 @@ def test_dict_grad_matches_index_add_bitwise(N, k_act, D, U):
     assert a is not None and torch.equal(a, b)
     ref = torch.zeros(U, D).index_add_(0, uid.cpu().reshape(-1).long(), (theta.unsqueeze(0) * gh.unsqueeze(1)).reshape(-1, D))
     _close(a, ref, "gdict", rtol=2e-4, atol=2e-4)
+    # with a designated id per hop (total minus the rest): the most frequent id, an arbitrary one, an out-of-range one
+    for dom in (torch.mode(uid, dim=0).values, torch.full((k_act,), U - 1), torch.full((k_act,), U + 5)):
+        uid_h = uid_full[:, :k_act]
+        uid_h._kp_dom = dom.to(torch.int32).to(dev).contiguous()
+        c = ops.dict_grad_raw(uid_h, U, theta.to(dev), gh.to(dev))
+        c2 = ops.dict_grad_raw(uid_h, U, theta.to(dev), gh.to(dev))
+        assert torch.equal(c, c2)
+        _close(c, ref, "gdict (designated id)", rtol=2e-4, atol=2e-4)
     assert ops.dict_grad_raw(uid, 4000, theta.to(dev), gh.to(dev)) is None      # does not fit LDS: the caller falls back
 
 
