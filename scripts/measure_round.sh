@@ -39,5 +39,7 @@ python scripts/pmc_summarize.py traffic $R/pmc_fetch $R/pmc_write $R/pmc_traffic
 mkdir -p profiles/r02 && cp $R/pmc_traffic.json profiles/r02/pmc_traffic.json && run bench_default
 python scripts/pmc_summarize.py sq $R/pmc_sq1 $R/pmc_sq1.json > /dev/null 2>&1; python scripts/pmc_summarize.py sq $R/pmc_sq2 $R/pmc_sq2.json > /dev/null 2>&1
 python scripts/pmc_summarize.py mfma $R/pmc_mfma $R/pmc_mfma.json > /dev/null 2>&1
-find $R -name "*agent_info.csv" -delete; find $R -name "*kernel_trace.csv" -size +20M -delete
+# (what is kept must fit the 64 MiB that travel back: the summaries above are made, the raw traces and counter dumps go)
+find $R -name "*agent_info.csv" -delete; find $R -name "*kernel_trace.csv" -delete; find $R -name "*counter_collection.csv" -delete
+du -sh $R | tail -1
 echo done
