@@ -591,7 +591,7 @@ SlabJob empty_job() {
 
 // slices for a slab of nslab rows: 64 (16 outputs per block) from 96 rows on, 16 (64 outputs) from 16 rows on, else 4 (256)
 void shape_job(SlabJob* j) {
-    j->lo = j->nslab >= 96 ? 4 : (j->nslab >= 16 ? 6 : 8);
+    j->lo = j->nslab >= 1024 ? 4 : (j->nslab >= 16 ? 6 : 8);
     const int64_t outs = (int64_t)1 << j->lo;
     j->nblocks = (int)((j->elems + outs - 1) / outs);
 }
