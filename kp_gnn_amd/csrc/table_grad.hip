@@ -558,6 +558,13 @@ slab_reduce_kernel(const SlabArgs a) {
     float s = 0.f;
     if (e < elems) {
         int b = slice;
+        for (; b + 7 * nsl < nslab; b += 8 * nsl) {          // eight independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(b + q * nsl) * elems + e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
         for (; b + 3 * nsl < nslab; b += 4 * nsl) {
             const float v0 = slab[(int64_t)b * elems + e], v1 = slab[(int64_t)(b + nsl) * elems + e];
             const float v2 = slab[(int64_t)(b + 2 * nsl) * elems + e], v3 = slab[(int64_t)(b + 3 * nsl) * elems + e];
@@ -591,7 +598,7 @@ SlabJob empty_job() {
 
 // slices for a slab of nslab rows: 64 (16 outputs per block) from 96 rows on, 16 (64 outputs) from 16 rows on, else 4 (256)
 void shape_job(SlabJob* j) {
-    j->lo = j->nslab >= 1024 ? 4 : (j->nslab >= 16 ? 6 : 8);
+    j->lo = j->nslab >= 1024 ? 4 : (j->nslab >= 128 ? 6 : 8);
     const int64_t outs = (int64_t)1 << j->lo;
     j->nblocks = (int)((j->elems + outs - 1) / outs);
 }
