@@ -292,7 +292,7 @@ typedef struct kpgnn_table_grad_desc {
     float* fuse_galphas;        /* device [D] or NULL */
     void* fuse_workspace;
     size_t fuse_workspace_bytes;
-    /* 1 (walk kernel only): the dictionary gradient is ADDED to what gdict / extra_out already hold (gdict += ...): a
+    /* 1: the dictionary gradient is ADDED to what gdict / extra_out already hold (gdict += ...): a
      * dictionary read by every layer collects its gradient in one buffer instead of one tensor per layer for the
      * framework to sum (7 add launches per step at L = 8). */
     int32_t accumulate_dict;

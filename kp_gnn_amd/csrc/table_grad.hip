@@ -820,13 +820,12 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(force != 1 || walk_fits, "table_grad: the walk kernel needs K <= 8, tiles of <= 64 (node, hop) rows and, "
                       "with a dictionary, the uid-sorted list of kpgnn_dict_tile_pack");
         if (force != 1 && (force == 2 || d->D <= 32 || !walk_fits)) {
-            if (d->accumulate_dict) return fail(KPGNN_EINVAL, "table_grad: accumulate_dict is served by the walk kernel only");
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
             if (rc != KPGNN_OK) return rc;
-            if (handled)
-                return slab_reduce(d->extra_slab, d->extra_slab ? d->extra_nslab : 0, d->extra_slab ? d->extra_elems : 0, d->extra_out,
-                                   d->extra_elems, nullptr, 0, nullptr, s, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, d->pending);
+            if (handled)    // (what the count-matrix kernel's own reduce does not cover: a deferred dictionary slab, a pending job)
+                return slab_reduce(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, s, 0, nullptr, d->extra_slab, d->extra_nslab,
+                                   d->extra_slab ? d->extra_elems : 0, d->extra_out, nullptr, d->accumulate_dict ? 2 : 0, d->pending);
         }
     }
     TgParams p;

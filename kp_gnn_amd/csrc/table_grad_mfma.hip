@@ -315,7 +315,7 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
     KPGNN_LAUNCH_CHECK("table_grad_mfma_kernel");
     *handled = true;
     return slab_reduce(p.slab, grid * pl.KQ, (int64_t)pl.R * p.D, d->gtable0, (int64_t)n0 * p.D, d->gtablek,
-                       (int64_t)nk * p.D, d->gdict, s);
+                       (int64_t)nk * p.D, d->gdict, s, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, d->accumulate_dict ? 1 : 0);
 }
 
 }  // namespace kpgnn

@@ -377,7 +377,8 @@ def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     return gd
 
 
-def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0, extra=None):
+def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0, extra=None,
+                   gdict_acc=None):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
     or the peripheral-dictionary gradient (theta/gh given: sum theta[k]*gh[i]; else: sum of g rows).
     kernel: 0 automatic, 1 register walk, 2 count-matrix product (parity tests).
@@ -408,8 +409,11 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         gtk = torch.empty((nk, D), dtype=torch.float32, device=dev) if nk > 0 else None
         d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
     if n_dict > 0:
-        gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
+        gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev) if gdict_acc is None else gdict_acc
         d.uid, d.uid_stride, d.gdict = uid.data_ptr(), uid.stride(0), gd.data_ptr()
+        if gdict_acc is not None:     # (a dictionary read by several layers: the gradient is added in place, see KHopAggregate)
+            assert gdict_acc.is_contiguous() and gdict_acc.dtype == torch.float32 and tuple(gdict_acc.shape) == (n_dict, D)
+            d.accumulate_dict = 1
         d.theta, d.gh = _ptr(theta), _ptr(gh)
         if K <= 8 and csr.nodes_per_tile * K <= 64:
             pack, kf = dict_tile_pack(csr, uid)
@@ -651,6 +655,7 @@ class KHopAggregate(torch.autograd.Function):
         want_gperiph = ctx.has_periph and ctx.needs_input_grad[3]
         want_gdict = ctx.n_dict > 0 and ctx.needs_input_grad[7]
         gtheta = gperiph = gdict = acc = None
+        acc_used = False
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
@@ -722,11 +727,16 @@ class KHopAggregate(torch.autograd.Function):
                     else:
                         gdict = dg
             if edges_here or dict_here:
+                if dict_here and ctx.dict_cell is not None and ctx.dict_cell.buf is not None:
+                    acc = ctx.dict_cell.buf          # later layers' share: this call's finishing launch adds to it
                 res = table_grad_raw(csr, g, ctx.n_code0, ctx.n_codek, edges=edges_here,
                                      uid=uid if dict_here else None, n_dict=ctx.n_dict if dict_here else 0,
-                                     theta=theta if fused else None, gh=gout if fused else None, extra=extra)
+                                     theta=theta if fused else None, gh=gout if fused else None, extra=extra,
+                                     gdict_acc=acc if dict_here else None)
                 if res is None and extra is not None:
                     raise _lib.KpgnnError("table_grad refused a shape after dict_grad deferred its reduction to it")
+                if res is not None and dict_here and acc is not None:
+                    acc_used = True
             if res is not None:
                 gt0, gtk = res[0], res[1]
                 gdict = res[2] if gdict is None else gdict
@@ -740,7 +750,9 @@ class KHopAggregate(torch.autograd.Function):
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
         if ctx.dict_cell is not None and want_gdict:
-            if acc is None and not done and ctx.dict_cell.buf is not None:
+            if acc_used:
+                acc = None                           # (already inside gdict)
+            elif acc is None and not done and ctx.dict_cell.buf is not None:
                 acc = ctx.dict_cell.buf
             if acc is not None:                      # (a path without the accumulating launch: add the parked share the plain way)
                 gdict = gdict + acc

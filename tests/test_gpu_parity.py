@@ -1565,3 +1565,41 @@ def test_deferred_reductions_give_the_same_bits(batch):
         assert (x is None) == (y is None), n
         if x is not None:
             assert torch.equal(x, y), (n, float((x - y).abs().max()))
+
+
+@pytest.mark.parametrize("D", [13, 104])
+def test_shared_dictionary_gradient_cell_unfused_paths(D):
+    """The same dictionary cell through the layers WITHOUT the fused combine (KP-GIN's sum mode, [N,k,D] states): the
+    dictionary gradient comes from kpgnn_table_grad's own dictionary rows - the count-matrix kernel at D = 13, the walk at
+    D = 104 - with accumulate_dict; equal to the unmarked run."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.khop_csr import KHopCSR
+    dev = _dev()
+    N, K, U = 900, 4, 9
+    E = 10 * N
+    g0 = torch.Generator().manual_seed(D)
+    ei = torch.randint(0, N, (2, E), generator=g0)
+    ea = torch.randint(1, 6, (E, K), generator=g0) * (torch.rand(E, K, generator=g0) < 0.5)
+    csr = KHopCSR.build(ei.to(dev), ea.to(dev), N)
+    base = dict(x=torch.randn(N, K, D, generator=g0), t0=torch.randn(6, D, generator=g0) * 0.3,
+                tk=torch.randn(6, D, generator=g0) * 0.3, ptab=torch.randn(U, D, generator=g0))
+    uid = torch.randint(0, U, (N, K), generator=g0, dtype=torch.int32).to(dev)
+    w = torch.randn(N, K, D, generator=g0).to(dev)
+
+    def run(shared):
+        t = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        ptab = t["ptab"] * 1.0
+        if shared:
+            ptab._kp_shared_grad = True
+        periph = ops.DictPeripheral(ptab, uid)
+        h = t["x"]
+        for _ in range(3):
+            h = torch.tanh(ops.khop_aggregate(h, csr, K, ops.MODE_SUM, t["t0"], t["tk"], periph))
+        (h * w).sum().backward()
+        cell = getattr(ptab, "_kp_grad_cell", None)
+        assert (cell is not None) == shared and (cell is None or cell.buf is None)
+        return t
+
+    a, b = run(True), run(False)
+    for k in base:
+        _close(a[k].grad, b[k].grad.cpu(), "grad " + k, rtol=2e-4, atol=2e-5)
