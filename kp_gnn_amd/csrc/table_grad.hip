@@ -823,9 +823,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
             bool handled = false;
             const int rc = table_grad_mfma(d, s, &handled);
             if (rc != KPGNN_OK) return rc;
-            if (handled)    // (what the count-matrix kernel's own reduce does not cover: a deferred dictionary slab, a pending job)
-                return slab_reduce(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, s, 0, nullptr, d->extra_slab, d->extra_nslab,
-                                   d->extra_slab ? d->extra_elems : 0, d->extra_out, nullptr, d->accumulate_dict ? 2 : 0, d->pending);
+            if (handled) return KPGNN_OK;   // (its finishing launch took the deferred dictionary slab and the pending job along)
         }
     }
     TgParams p;

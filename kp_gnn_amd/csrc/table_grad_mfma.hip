@@ -314,8 +314,10 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
 #undef KP_TGM
     KPGNN_LAUNCH_CHECK("table_grad_mfma_kernel");
     *handled = true;
+    // ONE finishing launch: this kernel's slabs, a deferred dictionary slab (extra_*) and a pending job of an earlier call
     return slab_reduce(p.slab, grid * pl.KQ, (int64_t)pl.R * p.D, d->gtable0, (int64_t)n0 * p.D, d->gtablek,
-                       (int64_t)nk * p.D, d->gdict, s, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, d->accumulate_dict ? 1 : 0);
+                       (int64_t)nk * p.D, d->gdict, s, 0, nullptr, d->extra_slab, d->extra_nslab, d->extra_slab ? d->extra_elems : 0,
+                       d->extra_out, nullptr, d->accumulate_dict ? 3 : 0, d->pending);
 }
 
 }  // namespace kpgnn
