@@ -14,7 +14,9 @@ Other workloads (the configurations of BASELINE.json that are parity cases for t
              --batch graphs per step (the script uses 1; --batch 100 = its whole set of N=100 graphs at once)
   zinc_gd16  configs[4]: KP-GIN' (GNNPrime: one KP-GIN layer + 16 GINE layers) K=16 L=17 h=96 kernel=gd, L1, Adam
 A "step" is one optimisation step (forward only for `regular`) on one pre-staged batch of B graphs per GPU (inputs and the
-K-hop CSR resident in HBM before the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
+K-hop CSR resident in HBM before the timed region).  --fresh-batches: the reference's epoch instead (train_ZINC.py:224: a
+shuffled DataLoader, no batch is seen twice) - a dataset of --dataset-graphs pre-transformed graphs stays resident in HBM
+(kp_gnn_amd/dataset.py) and EVERY timed step first collates a new random subset of it (kpgnn_collate, inside the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
 ranks, model replicated, one RCCL all-reduce of the flat gradient bucket per step; weak scaling.
 
 Rank 0 prints ONE JSON line with the contract fields plus
@@ -271,6 +273,11 @@ def main():
     ap.add_argument("--adam-in-graph", action="store_true",
                     help="1 GPU: capture the optimiser step (device-side step number) in the graph; measured 20 us SLOWER per step "
                          "than the eager launch behind the replay (its 480 blocks take a same-address ticket each)")
+    ap.add_argument("--fresh-batches", action="store_true",
+                    help="every step collates a NEW random subset of a resident dataset (shuffled epochs, drop_last), collate "
+                         "inside the timed region; launches are eager (batch shapes differ from step to step)")
+    ap.add_argument("--dataset-graphs", type=int, default=10000, help="--fresh-batches: graphs per rank in the resident dataset "
+                    "(10,000 = ZINC-12k's training split)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -320,16 +327,40 @@ def main():
         log(f"workload={args.workload} world={world} host threads/rank={threads} (os.cpu_count={os.cpu_count()})")
     t_data = time.perf_counter()
     batches = []
-    for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
-        seed0 = dp.shard_seed(rank, args.num_batches, i, args.batch)
-        b = make_batch(args, seed0, threads).to(device)
-        b.build_csr()
-        batches.append(b)
+    dataset = sampler = None
+    if args.fresh_batches:
+        # the whole (per-rank) dataset: host pre-transform once, CSR built once on the device, resident from here on
+        import numpy as np
+        from kp_gnn_amd.dataset import KHopDataset
+        if args.dataset_graphs < args.batch:
+            raise SystemExit("--dataset-graphs must be >= --batch")
+        saved, args.batch = args.batch, args.dataset_graphs
+        host = make_batch(args, dp.shard_seed(rank, 1, 0, args.dataset_graphs), threads)
+        args.batch = saved
+        dataset = KHopDataset.from_collated(host, host.node_ptr, device)
+        del host
+        rng = np.random.default_rng(1234 + rank)
+
+        def sampler(state={"perm": None, "pos": 0}):
+            """Shuffled epochs with drop_last, as DataLoader(shuffle=True) would (train_ZINC.py:224)."""
+            if state["perm"] is None or state["pos"] + args.batch > dataset.G:
+                state["perm"], state["pos"] = rng.permutation(dataset.G), 0
+            ids = state["perm"][state["pos"]:state["pos"] + args.batch]
+            state["pos"] += args.batch
+            return ids
+        batches = [dataset.collate(sampler()) for _ in range(args.num_batches)]   # warm-up / per-launch timing leg
+    else:
+        for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
+            seed0 = dp.shard_seed(rank, args.num_batches, i, args.batch)
+            b = make_batch(args, seed0, threads).to(device)
+            b.build_csr()
+            batches.append(b)
     torch.cuda.synchronize()
     t_data = time.perf_counter() - t_data
     if rank == 0:
-        log(f"{args.num_batches} batches x {args.batch} graphs built + CSR on device in {t_data:.1f}s "
-            f"(N={batches[0].num_nodes}, E_khop={batches[0].edge_index.shape[1]}, A={batches[0].csr.A})")
+        what = f"resident dataset of {args.dataset_graphs} graphs + " if args.fresh_batches else ""
+        log(f"{what}{args.num_batches} batches x {args.batch} graphs built + CSR on device in {t_data:.1f}s "
+            f"(N={batches[0].num_nodes}, E_khop={batches[0].csr.E}, A={batches[0].csr.A})")
 
     model = build_model(args, device)
     flat_grad = opt = None
@@ -352,7 +383,7 @@ def main():
         train_step(args, model, batches[i % len(batches)], opt, flat_grad, world)
     torch.cuda.synchronize()
     graphs = None
-    if not args.no_graph:
+    if not args.no_graph and not args.fresh_batches:
         # (a capture failure is an error, not a silent downgrade to eager launches: --no-graph asks for those)
         graphs = capture_graphs(args, model, batches, flat_grad, opt if (args.train and world == 1 and args.adam_in_graph) else None)
         for i in range(len(batches)):  # one replayed step per graph before timing
@@ -363,6 +394,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if sampler is not None:        # a batch no step has seen: collated from the resident dataset, here, in the timed region
+            out_t = train_step(args, model, dataset.collate(sampler()), opt, flat_grad, world)
+            continue
         j = i % len(batches)
         out_t = train_step(args, model, batches[j], opt, flat_grad, world, graphs[j] if graphs else None)
     barrier()
@@ -403,9 +437,12 @@ def main():
                                    + (f" {args.combine} combine" if args.train else "") + f", {what}"
                                    + (", dense peripheral tensor" if args.dense_peripheral else ""),
                        "graphs_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
-                       "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.edge_index.shape[1]),
+                       "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.csr.E),
                        "active_pairs_per_batch": int(b0.csr.A),
                        "parallelism": f"dp{world}", "launch": "hipGraph replay of fwd+bwd" if graphs else "eager",
+                       "batches": (f"fresh: every step collates a new shuffled subset of a resident {args.dataset_graphs}-graph dataset "
+                                   "(kpgnn_collate inside the timed region)") if args.fresh_batches
+                       else f"{args.num_batches} pre-staged batches cycled",
                        ("final_loss" if args.train else "mean_abs_output"): round(final, 5),
                        "data_build_s": round(t_data, 2)},
         }

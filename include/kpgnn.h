@@ -74,8 +74,9 @@ size_t kpgnn_csr_workspace_bytes(int64_t E, int64_t A, int64_t N, int32_t K);
  *   tile_ptr  int32[ceil(N/nodes_per_tile)+1]   (tile_ptr[last] = number of entries <= A)
  *   tile_pack uint32[A] (at most A entries are written) =
  *             table<<31 | code<<15 | node_in_tile<<12 | (multiplicity-1)<<6 | hop
- *   (table 0 = hop 0 -> hop1_edge_emb, table 1 = hops >= 1 -> hopk_edge_emb; codes < 2^16; multiplicity 1..64, longer
- *   runs are split). */
+ *   (table 0 = hop 0 -> hop1_edge_emb, table 1 = hops >= 1 -> hopk_edge_emb; codes < 2^16; multiplicity 1..64, a longer
+ *   run is split every 64 pairs counted from its own first pair - the list of a tile depends on that tile's pairs only,
+ *   which is what lets kpgnn_collate merge per-node lists built once per dataset into the very same list). */
 int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t* edge_attr, int64_t attr_stride,
                     int64_t E, int32_t K, int64_t N, int64_t A,
                     int32_t* rowptr_dst, int32_t* col_dst, uint16_t* code_dst,
@@ -89,6 +90,65 @@ int kpgnn_csr_build(const int64_t* edge_index, int64_t ei_stride, const int64_t*
  * among its waves by position, and inactive entries would leave most waves idle.  Static per batch and k. */
 int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t k,
                            int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
+
+/* All hop-prefix copies at once: for k = 1..num_prefix the entries with hop < k, in the same order (three launches in all,
+ * where kpgnn_tile_pack_filter takes three per k).  out_ptr int32[num_prefix][num_tiles+1], out_pack uint32[num_prefix][
+ * pack_stride] (pack_stride >= tile_ptr[num_tiles]), scratch int32[num_prefix][num_tiles]. */
+int kpgnn_tile_pack_prefixes(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t num_prefix,
+                             int64_t pack_stride, int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dataset-resident K-hop CSR + per-step collate (device).  Replaces the reference's storage / batching pair:
+ *   datasets/ZINC_dataset.py:139-140  `torch.save(self.collate(data_list), ...)` - PyG's (data, slices) store of the
+ *                                      pre-transformed dataset (tensors concatenated over graphs + per-graph offsets), and
+ *   train_ZINC.py:224,36-40            DataLoader(shuffle=True) -> Batch.from_data_list + `.to(device)` on EVERY step.
+ * The dataset's CSR (both orientations) and per-node table-gradient entry lists are built once - graph by graph the
+ * arrays kpgnn_csr_build emits, with node ids LOCAL to their graph and offsets RELATIVE to the graph's first pair / entry -
+ * and stay in HBM.  A batch of B graphs is then their concatenation plus offsets: no sort, no host synchronisation, no
+ * int64 traffic.  Result: bit-identical to kpgnn_csr_build on the PyG-collated batch of the same graphs in the same order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct kpgnn_dataset_view {
+    int32_t K;                  /* hops of the CSR */
+    int32_t G;                  /* graphs in the dataset */
+    const int64_t* node_ptr;    /* [G+1] first node of graph g in the node-level arrays (PyG slices['x']) */
+    const int64_t* pair_ptr;    /* [G+1] first active (edge,hop) pair of graph g; the same offsets serve both orientations */
+    const int64_t* ent_ptr;     /* [G+1] first table-gradient entry of graph g (NULL: no entry lists) */
+    const int32_t* rowptr_dst;  /* [Nd*K] first pair of segment (node, hop) keyed by destination, relative to pair_ptr[g] */
+    const int32_t* rowptr_src;  /* [Nd*K] the same keyed by source */
+    const int32_t* col_dst;     /* [Ad] other endpoint of a pair, node id local to its graph */
+    const int32_t* col_src;
+    const uint16_t* code_dst;   /* [Ad] edge code of a pair */
+    const uint16_t* code_src;
+    const int32_t* ent_rel;     /* [Nd] first entry of a node, relative to ent_ptr[g] */
+    const uint32_t* ent;        /* per-node entry lists = kpgnn_csr_build's tile_pack with nodes_per_tile = 1 */
+} kpgnn_dataset_view;
+
+typedef struct kpgnn_row_gather { const void* src; void* dst; int32_t row_bytes; } kpgnn_row_gather;
+
+typedef struct kpgnn_collate_desc {
+    kpgnn_dataset_view ds;
+    int32_t B;                  /* graphs in the batch */
+    int32_t N;                  /* its nodes, pairs and entries: sums of per-graph counts the host keeps (launch sizes;  */
+    int64_t A;                  /*   the kernels themselves read them from the header)                                  */
+    int64_t n_ent;
+    /* device int32[4B+3]: ids[B] (dataset graph of batch slot b) | node_base[B+1] | pair_base[B+1] | ent_base[B+1], the three
+     * exclusive prefix sums of the chosen graphs' node / pair / entry counts (last element = N / A / n_ent) */
+    const int32_t* hdr;
+    int32_t* rowptr_dst; int32_t* col_dst; uint16_t* code_dst;    /* int32[N*K+1], int32[A], uint16[A] */
+    int32_t* rowptr_src; int32_t* col_src; uint16_t* code_src;
+    int64_t* batch;             /* [N] batch slot of every node (PyG's Batch.batch) */
+    int32_t* node_src;          /* [N] dataset node of every batch node */
+    /* table-gradient entry list of the batch (tile_ptr NULL: skipped) and its hop-prefix copies for k = 1..num_prefix
+     * (as kpgnn_tile_pack_prefixes lays them out, pack_stride = n_ent) */
+    int32_t nodes_per_tile; int32_t* tile_ptr; uint32_t* tile_pack;
+    int32_t* ent_node_ptr;      /* [N+1] scratch (first entry of every batch node) */
+    int32_t num_prefix; int32_t* prefix_ptr; uint32_t* prefix_pack; int32_t* prefix_scratch;
+    /* dense per-node / per-graph attributes: dst[i] = src[node_src[i]] (node rows), dst[b] = src[ids[b]] (graph rows) */
+    int32_t n_node_rows; kpgnn_row_gather node_rows[8];
+    int32_t n_graph_rows; kpgnn_row_gather graph_rows[8];
+} kpgnn_collate_desc;
+
+int kpgnn_collate(const kpgnn_collate_desc* d, kpgnn_stream_t stream);
 
 /* loss[0] = mean_i |score[i] - y[i]| (kind 0; train_ZINC.py:42) or mean_i (score[i] - y[i])^2 (kind 1; train_qm9.py:96) and,
  * when dscore != NULL, dscore[i] = d loss / d score[i].  score, y: device [n] contiguous.  One launch, one block, fixed
@@ -286,7 +346,7 @@ typedef struct kpgnn_table_grad_desc {
     const int32_t* fuse_uid;    /* device [N, fuse_uid_stride] */
     int64_t fuse_uid_stride;
     int32_t fuse_n_dict;
-    float* fuse_g;              /* device [N,K,D] contiguous (written) */
+    float* fuse_g;              /* device, written: element (i,k,c) at i*g_sn + k*g_sk + c (even strides >= D; [N,K,D] contiguous or hop-major [K][N][D]) */
     float* fuse_gtheta;         /* device [K,D] or NULL */
     const float* fuse_alphas;   /* device [D] or NULL */
     float* fuse_galphas;        /* device [D] or NULL */

@@ -192,6 +192,31 @@ class PoolDesc(ctypes.Structure):
     ]
 
 
+class DatasetView(ctypes.Structure):
+    _fields_ = [
+        ("K", c_i32), ("G", c_i32), ("node_ptr", c_vp), ("pair_ptr", c_vp), ("ent_ptr", c_vp),
+        ("rowptr_dst", c_vp), ("rowptr_src", c_vp), ("col_dst", c_vp), ("col_src", c_vp),
+        ("code_dst", c_vp), ("code_src", c_vp), ("ent_rel", c_vp), ("ent", c_vp),
+    ]
+
+
+class RowGather(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("row_bytes", c_i32)]
+
+
+class CollateDesc(ctypes.Structure):
+    _fields_ = [
+        ("ds", DatasetView), ("B", c_i32), ("N", c_i32), ("A", c_i64), ("n_ent", c_i64), ("hdr", c_vp),
+        ("rowptr_dst", c_vp), ("col_dst", c_vp), ("code_dst", c_vp),
+        ("rowptr_src", c_vp), ("col_src", c_vp), ("code_src", c_vp),
+        ("batch", c_vp), ("node_src", c_vp),
+        ("nodes_per_tile", c_i32), ("tile_ptr", c_vp), ("tile_pack", c_vp), ("ent_node_ptr", c_vp),
+        ("num_prefix", c_i32), ("prefix_ptr", c_vp), ("prefix_pack", c_vp), ("prefix_scratch", c_vp),
+        ("n_node_rows", c_i32), ("node_rows", RowGather * 8),
+        ("n_graph_rows", c_i32), ("graph_rows", RowGather * 8),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/kpgnn.h declares
 SIGNATURES = {
     "kpgnn_abi_version": (ctypes.c_int, []),
@@ -211,6 +236,8 @@ SIGNATURES = {
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "kpgnn_tile_pack_prefixes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "kpgnn_collate": (ctypes.c_int, [ctypes.POINTER(CollateDesc), c_vp]),
     "kpgnn_regression_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_double, c_vp]),

@@ -44,12 +44,13 @@ def collate_khop(node_ptr, edge_ptr, edge_index, edge_attr, x, khop_args, y=None
     xt = torch.as_tensor(x)
     if xt.dim() == 1:
         xt = xt.view(-1, 1)
-    if edge_attr is None:
-        edge_attr = None
-    return KHopBatch(x=xt, edge_index=out["edge_index"], edge_attr=out["edge_attr"], pe_attr=out["pe_attr"],
-                     peripheral_edge_attr=out["peripheral_edge_attr"],
-                     peripheral_configuration_attr=out["peripheral_configuration_attr"], batch=out["batch"], y=y,
-                     num_graphs=len(node_ptr) - 1)
+    b = KHopBatch(x=xt, edge_index=out["edge_index"], edge_attr=out["edge_attr"], pe_attr=out["pe_attr"],
+                  peripheral_edge_attr=out["peripheral_edge_attr"],
+                  peripheral_configuration_attr=out["peripheral_configuration_attr"], batch=out["batch"], y=y,
+                  num_graphs=len(node_ptr) - 1)
+    b.node_ptr = out["node_ptr"].numpy()          # per-graph slices (PyG's slices['x']): what KHopDataset.from_collated needs
+    b.edge_ptr = out["edge_ptr"].numpy()
+    return b
 
 
 def synthetic_zinc_batch(num_graphs, seed0, K=8, kernel="spd", num_threads=0):

@@ -74,6 +74,31 @@ def _packed_peripheral_index(pea, pca, sizes):
     return rec[1:]
 
 
+_COL_OFFSETS = {}
+
+
+def _dataset_peripheral_index(pd, use_e, use_c, sizes):
+    """The same four values as _packed_peripheral_index for a batch collated from a resident dataset: the dictionary rows
+    are the DATASET's distinct tuples (static), the batch carries int32 ids into them; the range check runs on the host
+    against the dataset-wide column maxima (no device round trip, nothing per batch but the ids themselves)."""
+    T, Hc = pd.pdict.T, pd.pdict.Hc
+    rows, col_max = pd.pdict.select(use_e, use_c)
+    table_of_col = ([0, 1] * T if use_e else []) + list(range(2 if use_e else 0, (2 if use_e else 0) + (Hc if use_c else 0)))
+    for c, t in enumerate(table_of_col):
+        if col_max[c] >= sizes[t]:
+            raise IndexError("peripheral attribute index out of range for its embedding table")
+    key = (tuple(sizes), tuple(table_of_col), rows.device)
+    col_offset = _COL_OFFSETS.get(key)
+    if col_offset is None:
+        starts = [0]
+        for n in sizes:
+            starts.append(starts[-1] + n)
+        col_offset = _COL_OFFSETS[key] = torch.tensor([starts[t] for t in table_of_col], dtype=torch.int32, device=rows.device)
+    if rows.shape[0] <= MAX_DICT_ROWS:
+        return None, col_offset, rows, pd.uid
+    return rows[pd.uid.reshape(-1).long()].contiguous(), col_offset, None, None     # (dense rows: a dictionary too large for LDS)
+
+
 # ------------------------------------------------------------------------------------------------ small pieces
 def _get(data, name):
     try:
@@ -291,8 +316,9 @@ class _KHopBody(nn.Module):
         the projected (tiny) tables, gates and biases folded in (ops.table_gather_sum).  The int64 index
         tensors are packed to uint16 once per batch object."""
         pea, pca = _get(data, "peripheral_edge_attr"), _get(data, "peripheral_configuration_attr")
-        use_e = (not self.wo_peripheral_edge) and pea is not None
-        use_c = (not self.wo_peripheral_configuration) and pca is not None
+        pd = _get(data, "peripheral_dict")        # dataset.BatchPeripheral: dictionary ids collated from a resident dataset
+        use_e = (not self.wo_peripheral_edge) and (pea is not None or pd is not None)
+        use_c = (not self.wo_peripheral_configuration) and (pca is not None or pd is not None)
         if not (use_e or use_c):
             return like.new_zeros(num_nodes, self.K, self._periph_width)
         W = self._periph_width
@@ -300,7 +326,7 @@ class _KHopBody(nn.Module):
         encs, sizes = [], []
         if use_e:
             enc = self.peripheral_edge_embedding
-            encs.append((enc, self.pew, pea.shape[-2]))
+            encs.append((enc, self.pew, pea.shape[-2] if pea is not None else pd.pdict.T))
             sizes.extend(emb.num_embeddings for emb in enc.embedding_list)
         if use_c:
             enc = self.peripheral_configuration_embedding
@@ -318,7 +344,10 @@ class _KHopBody(nn.Module):
                 tables.append(_projected_tables(enc, g))
                 bias = bias + g * mult * enc.proj.bias
             table = torch.cat(tables, dim=0)
-        idx, col_offset, uidx, uid = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
+        if pd is not None:
+            idx, col_offset, uidx, uid = _dataset_peripheral_index(pd, use_e, use_c, sizes)
+        else:
+            idx, col_offset, uidx, uid = _packed_peripheral_index(pea if use_e else None, pca if use_c else None, sizes)
         if uidx is not None:
             # dictionary form: the distinct index tuples are few (25 for a 2048-molecule batch), so P is a
             # [U,W] table + a static int32 uid per (node,hop); the layers' kernels read / differentiate that

@@ -163,7 +163,7 @@ rowptr_unpack_kernel(const uint32_t* __restrict__ keys, const uint64_t* __restri
 // measured slower (90 vs 78 us at k = 8) although it walks fewer entries.
 //   key   = tile<<26 | table<<25 | code<<9 | hop<<3 | node_in_tile          (sorted, K <= 62; table = hop > 0)
 //   entry = table<<31 | code<<15 | node_in_tile<<12 | (multiplicity-1)<<6 | hop
-// Runs are cut every 64 sorted positions, so a multiplicity fits its 6 bits.
+// Runs are cut every 64 entries (counted from the run's first entry), so a multiplicity fits its 6 bits.
 __global__ void __launch_bounds__(kThreads)
 expand_tile_keys_kernel(const int64_t* __restrict__ ei, int64_t ei_stride, const int64_t* __restrict__ attr,
                         int64_t attr_stride, int64_t E, int K, int nodes_per_tile,
@@ -183,8 +183,29 @@ expand_tile_keys_kernel(const int64_t* __restrict__ ei, int64_t ei_stride, const
     }
 }
 
+// A run of equal keys is cut every 64 entries COUNTED FROM ITS OWN FIRST ENTRY (not from the list position): the merged list
+// of a tile is then a function of the tile's pairs alone, so per-node lists built once per dataset can be merged into the
+// same list at collate time (collate.hip).  The first entry of a run is found by galloping back, then bisecting.
 __device__ __forceinline__ bool tile_run_start(const uint64_t* __restrict__ keys, int64_t i) {
-    return i == 0 || (i & 63) == 0 || keys[i] != keys[i - 1];
+    if (i == 0) return true;
+    const uint64_t key = keys[i];
+    if (keys[i - 1] != key) return true;
+    int64_t step = 2, lo;                 // keys[i - 1] == key
+    for (;;) {
+        lo = i - step;
+        if (lo <= 0) { lo = 0; break; }
+        if (keys[lo] != key) break;
+        step <<= 1;
+    }
+    // invariant: keys[hi] == key; keys[lo] != key unless lo == 0 reached by clamping
+    int64_t hi = i - (step >> 1);
+    if (keys[lo] == key) hi = lo;
+    else
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] == key) hi = mid; else lo = mid;
+        }
+    return ((i - hi) & 63) == 0;          // hi = first entry of the run
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -201,7 +222,7 @@ tile_emit_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ 
     if (i >= A || !tile_run_start(keys, i)) return;
     const uint64_t key = keys[i];
     uint32_t len = 1;
-    while (i + len < A && ((i + len) & 63) != 0 && keys[i + len] == key) ++len;
+    while (i + len < A && len < 64 && keys[i + len] == key) ++len;
     const uint32_t hop = (uint32_t)(key >> 3) & 63u, code = (uint32_t)(key >> 9) & 0xFFFFu, nit = (uint32_t)key & 7u;
     pack[idx[i]] = ((hop > 0 ? 1u : 0u) << 31) | (code << 15) | (nit << 12) | ((len - 1) << 6) | hop;
 }

@@ -42,7 +42,8 @@ struct TgParams {
     // FUSE (combine backward computed here instead of read from g): S, the dictionary for the theta gradient, outputs
     const float* f_pre;      // [N,K,D] S saved by the forward
     const float* f_ptab; const int32_t* f_uid; int64_t f_uid_stride; int f_U;   // P = ptab[uid] (theta gradient only)
-    float* f_g;              // [N,K,D] dL/dS out
+    float* f_g;              // dL/dS out: element (i, k, c) at i * f_g_sn + k * f_g_sk + c
+    int64_t f_g_sn, f_g_sk;  //   ([N,K,D] contiguous, or hop-major [K][N][D]: one contiguous [N,D] slab per hop for agg_bwd's gather)
     float* f_gth;            // [gridDim.x][K][D] theta-gradient partials, or NULL
 };
 
@@ -318,7 +319,7 @@ table_grad_kernel(const TgParams p, int AS) {
                     gth_a = fmaf(gh2.x, a0 + pr.x, gth_a);
                     gth_b = fmaf(gh2.y, a1 + pr.y, gth_b);
                     if (col_ok) {
-                        *reinterpret_cast<float2*>(p.f_g + (node * K + fk) * (int64_t)D + c) = make_float2(g0, g1);
+                        *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + fk * p.f_g_sk + c) = make_float2(g0, g1);
                         *reinterpret_cast<float2*>(tile + (n * K + fk) * D + c) = make_float2(g0, g1);
                     }
                 }
@@ -786,6 +787,9 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         p.uid = d->uid; p.uid_stride = d->uid_stride; p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.theta = d->theta; p.gh = d->gh;
         p.f_pre = d->fuse_pre; p.f_ptab = d->fuse_uid ? d->fuse_ptab : nullptr; p.f_uid = d->fuse_uid; p.f_uid_stride = d->fuse_uid_stride;
         p.f_U = d->fuse_uid ? d->fuse_n_dict : 0; p.f_g = d->fuse_g; p.f_gth = d->fuse_gtheta ? (float*)d->fuse_workspace : nullptr;
+        p.f_g_sn = d->g_sn; p.f_g_sk = d->g_sk;
+        KPGNN_REQUIRE(p.f_g_sn >= d->D && p.f_g_sn % 2 == 0 && p.f_g_sk % 2 == 0 && (d->K == 1 || p.f_g_sk >= d->D),
+                      "table_grad(fused combine): fuse_g strides (g_sn=%lld, g_sk=%lld) must be even and >= D", (long long)p.f_g_sn, (long long)p.f_g_sk);
         Plan pl;
         int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl, 8 + p.f_U);
         if (rc != KPGNN_OK) return rc;
@@ -836,6 +840,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
     // (a list built for all K hops serves every layer: entries of hops >= d->K are skipped)
     p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.KD = d->dict_pack_K;
     p.f_pre = nullptr; p.f_ptab = nullptr; p.f_uid = nullptr; p.f_uid_stride = 0; p.f_U = 0; p.f_g = nullptr; p.f_gth = nullptr;
+    p.f_g_sn = p.f_g_sk = 0;
     Plan pl;
     int rc = make_plan(p.N, p.K, p.D, p.NT, p.n0, p.nk, p.U, &pl);
     if (rc != KPGNN_OK) return rc;

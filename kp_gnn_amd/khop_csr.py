@@ -23,7 +23,7 @@ class KHopCSR:
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
                  "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
-                 "_dict_packs", "_tile_lists", "device")
+                 "_dict_packs", "_tile_lists", "_keep", "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
 
@@ -36,6 +36,8 @@ class KHopCSR:
     def tile_list(self, k_active):
         """(tile_ptr, tile_pack) restricted to hops < k_active (kpgnn_tile_pack_filter): what kpgnn_table_grad walks for a
         layer that aggregates a hop prefix.  Static per batch; built on first use and kept."""
+        if self.tile_ptr is None:
+            raise _lib.KpgnnError("this CSR was built without the table-gradient entry list")
         if k_active >= self.K:
             return self.tile_ptr, self.tile_pack
         hit = self._tile_lists.get(k_active)
@@ -71,7 +73,9 @@ class KHopCSR:
         return self._dis
 
     @staticmethod
-    def build(edge_index, edge_attr, num_nodes):
+    def build(edge_index, edge_attr, num_nodes, nodes_per_tile=NODES_PER_TILE):
+        """nodes_per_tile: tile size of the table-gradient entry list (1..8; 1 = per-node lists, what KHopDataset keeps);
+        None skips the list."""
         if not edge_index.is_cuda:
             raise _lib.KpgnnError("KHopCSR.build needs device tensors: the HIP path has no CPU fallback")
         lib = _lib.load()
@@ -111,16 +115,17 @@ class KHopCSR:
             c.col_src = torch.empty(max(c.A, 1), **i32)
             c.code_dst = torch.empty(max(c.A, 1), dtype=torch.int16, device=dev)  # uint16 payload
             c.code_src = torch.empty(max(c.A, 1), dtype=torch.int16, device=dev)
-            c.nodes_per_tile = KHopCSR.NODES_PER_TILE
+            c.nodes_per_tile = nodes_per_tile if nodes_per_tile is not None else KHopCSR.NODES_PER_TILE
             ntiles = (N + c.nodes_per_tile - 1) // c.nodes_per_tile
-            c.tile_ptr = torch.empty(ntiles + 1, **i32)
-            c.tile_pack = torch.empty(max(c.A, 1), **i32)  # uint32 payload
+            c.tile_ptr = torch.empty(ntiles + 1, **i32) if nodes_per_tile is not None else None
+            c.tile_pack = torch.empty(max(c.A, 1), **i32) if nodes_per_tile is not None else None  # uint32 payload
             ws_bytes = lib.kpgnn_csr_workspace_bytes(E, c.A, N, K)
             ws = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.kpgnn_csr_build(edge_index.data_ptr(), ei_stride, edge_attr.data_ptr(), at_stride, E, K, N,
                                            c.A, c.rowptr_dst.data_ptr(), c.col_dst.data_ptr(), c.code_dst.data_ptr(),
                                            c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr(),
-                                           c.nodes_per_tile, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(),
+                                           c.nodes_per_tile, None if c.tile_ptr is None else c.tile_ptr.data_ptr(),
+                                           None if c.tile_pack is None else c.tile_pack.data_ptr(),
                                            ws.data_ptr(), ctypes.c_size_t(ws.numel()), stream), "kpgnn_csr_build")
         return c
 

@@ -478,7 +478,6 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
         d.accumulate_dict = 1
     tptr, tpack = csr.tile_list(K)
     d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
-    d.g_sn, d.g_sk = K * D, D
     gh = gh.contiguous()
     theta = theta.contiguous()
     d.theta, d.gh = theta.data_ptr(), gh.data_ptr()
@@ -487,7 +486,10 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
     d.gtable0, d.gtablek = gt0.data_ptr(), _ptr(gtk)
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
     d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
-    g = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+    # dL/dS leaves hop-major ([K][N][D]: the transposed gather of kpgnn_aggregate_bwd then reads one contiguous [N,D] slab
+    # per hop, like the forward's hop slots, instead of rows K*D floats apart - 1.5x of its bytes reached HBM that way)
+    g = torch.empty((K, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
+    d.g_sn, d.g_sk = g.stride(0), g.stride(1)
     d.fuse_pre, d.fuse_g = pre.data_ptr(), g.data_ptr()
     if uid is not None and ptab is not None:
         d.fuse_ptab, d.fuse_uid, d.fuse_uid_stride, d.fuse_n_dict = ptab.data_ptr(), uid.data_ptr(), uid.stride(0), ptab.shape[0]
@@ -940,6 +942,15 @@ def table_gather_sum(table, bias, idx, col_offset):
 
 
 _I16 = "_kpgnn_idx16"
+_ZERO_OFF = {}
+
+
+def _zero_offset(dev):
+    """One int32 zero per device: the column offset of a single-table gather-sum."""
+    t = _ZERO_OFF.get(dev)
+    if t is None:
+        t = _ZERO_OFF[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
 
 
 class _ZeroRowGrad(torch.autograd.Function):
@@ -974,6 +985,18 @@ def embedding_rows(weight, idx, padding_idx=None):
                                   "backward cannot be captured in a hipGraph (host read-back); run eagerly")
         return torch.nn.functional.embedding(idx.long(), weight, padding_idx=padding_idx)
     rec = getattr(idx, _I16, None)
+    if rec is None or rec[0] != (idx._version, R):
+        # a batch collated from a resident dataset (dataset.KHopDataset.collate) carries int16 indices whose dataset-wide
+        # maximum is known on the host: no device round trip for the range check
+        pre = getattr(idx, "_kp_index_bound", None)
+        if pre is not None and pre[0] == idx._version and idx.dtype == torch.int16 and idx.is_contiguous():
+            if pre[1] >= R:
+                raise IndexError(f"embedding index {pre[1]} out of range for a table with {R} rows")
+            rec = ((idx._version, R), idx.reshape(-1, 1), _zero_offset(idx.device))
+            try:
+                setattr(idx, _I16, rec)
+            except Exception:  # pragma: no cover
+                pass
     if rec is None or rec[0] != (idx._version, R):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.KpgnnError("embedding_rows: first use of an index tensor inside a hipGraph capture (its range "
