@@ -563,6 +563,13 @@ typedef struct kpgnn_wgrad_desc {
      * launching it (kpgnn_reduce_job above; for kpgnn_linear_wgrad_pair: a->defer, one job for all four outputs).  dw / db
      * are NOT written until the job has run. */
     kpgnn_reduce_job* defer;
+    /* Optional ReLU mask of dy on load (device [N,O], rows dy_stride apart): dy' = dy where dy_mask > 0, else 0 - the gradient
+     * behind a ReLU whose OUTPUT was saved (the jumping-knowledge projection), without materialising the masked gradient. */
+    const float* dy_mask;
+    /* Optional (device int32[1]): the number of LIVE rows, <= N.  A launch captured in a hipGraph for a batch CAPACITY of N
+     * rows then serves batches of any size up to it (kpgnn_collate leaves the count in its header): rows >= *n_dyn are
+     * neither read nor summed.  NULL: all N rows. */
+    const int32_t* n_dyn;
 } kpgnn_wgrad_desc;
 
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);
@@ -570,6 +577,13 @@ int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stream);
 /* Two weight gradients with the same (O, I) in ONE launch + one ordered reduction (the two Linears of a
  * Linear-BatchNorm-ReLU x2 MLP): workspace >= 2 * kpgnn_wgrad_workspace_bytes(O, I), taken from a. */
 int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wgrad_desc* b, kpgnn_stream_t stream);
+/* Grouped-K weight gradient: the Linear's input was the CONCATENATION of `group` (<= 16) states x_l [N,I] that live in
+ * separate tensors (the bodies' jumping-knowledge projection, models/GNNs.py:216-218 / :455-457: cat(h_list) -> Linear):
+ * dw [O, group*I] with dw[:, l*I:(l+1)*I] = dy^T x_l, db = sum dy.  d->x is ignored (x_group is a HOST array of device
+ * pointers, rows d->x_stride apart); one launch (the column blocks run side by side and share dy) + one ordered reduction.
+ * workspace >= kpgnn_wgrad_group_workspace_bytes(O, I, group).  Needs 16-B aligned operands, O % 4 == I % 4 == 0, O <= 128. */
+size_t kpgnn_wgrad_group_workspace_bytes(int32_t O, int32_t I, int32_t group);
+int kpgnn_linear_wgrad_group(const kpgnn_wgrad_desc* d, const float* const* x_group, int32_t group, kpgnn_stream_t stream);
 
 /* y = x W^T (+ b) for tall-skinny x ([N, I], N ~ 50k, I, O <= 256) on the fp32 matrix cores: the nn.Linear
  * forward of the layers' MLPs, and - called with W^T - their input gradient dx = dy W.  Each wave keeps its
@@ -589,9 +603,27 @@ typedef struct kpgnn_linear_desc {
      * y_block_stride floats apart.  The input gradient of a jumping-knowledge projection (models/GNNs.py:216-218) then
      * comes out as one contiguous [N,H] matrix per layer state instead of [N, S*H] column slices.  0: plain [N,O]. */
     int32_t y_block_cols; int64_t y_block_stride;
+    /* Optional (O > 128 only) ReLU mask of x on load (device [N,I], rows x_stride apart): x' = x where x_mask > 0, else 0. */
+    const float* x_mask;
+    const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N), as in kpgnn_wgrad_desc; O > 128 only */
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
+
+/* y = act(sum_l x_l W[:, l*I:(l+1)*I]^T + b): nn.Linear over the concatenation of `group` (<= 16) states x_l [N,I] that live
+ * in SEPARATE tensors - the bodies' jumping-knowledge projection `output_proj(torch.cat(h_list, dim=-1))`
+ * (models/GNNs.py:216-218, :455-457, :703-705; ReLU from the Sequential at :58-59) without the concatenated copy: the
+ * GEMM's K-loop runs over the state pointers.  w: device [O, group*I] contiguous; y: device [N,O] contiguous.
+ * O <= 128, O % 4 == 0, I in {32, 64, 96, 104, 128}, 16-B aligned operands. */
+typedef struct kpgnn_linear_group_desc {
+    int64_t N;
+    int32_t O, I, group;
+    const float* x[16]; int64_t x_stride;
+    const float* w; const float* bias; float* y;
+    int32_t relu;
+    const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N) */
+} kpgnn_linear_group_desc;
+int kpgnn_linear_group_fwd(const kpgnn_linear_group_desc* d, kpgnn_stream_t stream);
 
 /* The same GEMM with BatchNorm work folded into the tile's load and store phases (csrc/lin_fused.h), so that the
  * Linear-BatchNorm-ReLU x2 MLP (KPGINplus.py:25-30, gine.py:31-38) is 3 launches forward and 5 backward instead of

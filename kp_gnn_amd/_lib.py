@@ -118,7 +118,7 @@ class WgradDesc(ctypes.Structure):
         ("dy", c_vp), ("dy_stride", c_i64), ("x", c_vp), ("x_stride", c_i64),
         ("dw", c_vp), ("db", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("x_mean", c_vp), ("x_invstd", c_vp), ("x_gamma", c_vp), ("x_beta", c_vp), ("x_relu", c_i32),
-        ("defer", c_vp),
+        ("defer", c_vp), ("dy_mask", c_vp), ("n_dyn", c_vp),
     ]
 
 
@@ -151,7 +151,14 @@ class LinearDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("x", c_vp), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64),
-        ("w_transposed", c_i32), ("y_block_cols", c_i32), ("y_block_stride", c_i64),
+        ("w_transposed", c_i32), ("y_block_cols", c_i32), ("y_block_stride", c_i64), ("x_mask", c_vp), ("n_dyn", c_vp),
+    ]
+
+
+class LinearGroupDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i64), ("O", c_i32), ("I", c_i32), ("group", c_i32),
+        ("x", c_vp * 16), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("relu", c_i32), ("n_dyn", c_vp),
     ]
 
 
@@ -253,6 +260,8 @@ SIGNATURES = {
     "kpgnn_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "kpgnn_linear_wgrad": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp]),
     "kpgnn_linear_wgrad_pair": (ctypes.c_int, [ctypes.POINTER(WgradDesc), ctypes.POINTER(WgradDesc), c_vp]),
+    "kpgnn_wgrad_group_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
+    "kpgnn_linear_wgrad_group": (ctypes.c_int, [ctypes.POINTER(WgradDesc), c_vp, c_i32, c_vp]),
     "kpgnn_linear_bn": (ctypes.c_int, [ctypes.POINTER(LinearBnDesc), c_vp]),
     "kpgnn_enc_tables_fwd": (ctypes.c_int, [ctypes.POINTER(EncTablesDesc), c_vp]),
     "kpgnn_enc_tables_bwd": (ctypes.c_int, [ctypes.POINTER(EncTablesDesc), c_vp]),
@@ -263,6 +272,7 @@ SIGNATURES = {
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
+    "kpgnn_linear_group_fwd": (ctypes.c_int, [ctypes.POINTER(LinearGroupDesc), c_vp]),
     "kpgnn_geo_theta_fwd": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_geo_theta_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_hop_mlp_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32, c_i32, c_i32, c_i32]),

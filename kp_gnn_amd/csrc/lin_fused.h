@@ -155,13 +155,19 @@ lin_fused_kernel(const LinFParams p) {
     const bool act_i = tid < NAI;
     const int64_t tiles = (p.N + ROWS - 1) / ROWS;
     float4 pf[PFI];
+    // The loads are UNCONDITIONAL, from rows clamped to N - 1 (threads without a slot and rows beyond N read a valid row whose
+    // values only ever reach tile rows that are never stored or summed).  A predicated load is a branch, and with branches
+    // around its vector-memory instructions the compiler cannot count them: it put `s_waitcnt vmcnt(0)` in front of the
+    // first MFMA of every tile - i.e. it waited for the NEXT tile's rows before computing this one (round 2: "the phases of a
+    // tile do not overlap").
+    const int64_t lastrow = p.N - 1;
     auto issue = [&](int64_t tl) {                    // PRO 0 / 1: the next tile travels in registers
         const int64_t r0 = tl * ROWS;
-        const float* base = p.x + r0 * I + 4 * tid;
 #pragma unroll
         for (int j = 0; j < PFI; ++j) {
-            pf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act_i && rli + j * RLI < ROWS && r0 + rli + j * RLI < p.N) pf[j] = ld4(base + (int64_t)j * NAI * 4);
+            int64_t r = r0 + rli + j * RLI;
+            r = r < lastrow ? r : lastrow;
+            pf[j] = ld4(p.x + r * I + 4 * cgi);
         }
     };
     auto commit = [&]() {
@@ -192,12 +198,11 @@ lin_fused_kernel(const LinFParams p) {
                         q0 = ld4(cin + 10 * I + 4 * cgi); q1 = ld4(cin + 11 * I + 4 * cgi); }
         float4 dz[PFI], xs[PFI];
 #pragma unroll
-        for (int j = 0; j < PFI; ++j) {
-            dz[j] = make_float4(0.f, 0.f, 0.f, 0.f); xs[j] = dz[j];
-            if (act_i && rli + j * RLI < ROWS && r0 + rli + j * RLI < p.N) {
-                dz[j] = ld4(p.x + r0 * I + 4 * tid + (int64_t)j * NAI * 4);
-                xs[j] = ld4(p.x2 + r0 * I + 4 * tid + (int64_t)j * NAI * 4);
-            }
+        for (int j = 0; j < PFI; ++j) {              // (unconditional, clamped rows: see `issue`; rows beyond N are zeroed below)
+            int64_t r = r0 + rli + j * RLI;
+            r = r < lastrow ? r : lastrow;
+            dz[j] = ld4(p.x + r * I + 4 * cgi);
+            xs[j] = ld4(p.x2 + r * I + 4 * cgi);
         }
 #pragma unroll
         for (int j = 0; j < PFI; ++j) {
@@ -224,6 +229,26 @@ lin_fused_kernel(const LinFParams p) {
     const bool act_o = tid < NAO;
     double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};   // EPI 1 / 2 column partials of this thread
 
+    // (a use of the weight strip in front of the loop: the wait for its loads happens HERE, once - otherwise the compiler,
+    //  unable to tell at the loop header whether they have landed, waits for ALL vector-memory operations before the first MFMA
+    //  of every tile, the next tile's prefetch included)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a[ks]));
+    // this lane's bias values (4 groups of 4 outputs), fetched once: inside the tile loop each of the four loads was a
+    // dependent round trip in front of the LDS staging of its group
+    // (the backward variants, PRO >= 2, carry no bias - the host rejects one - and have no registers to spare for it)
+    constexpr bool HAS_BIAS = PRO < 2;
+    float4 bias4[HAS_BIAS ? 4 : 1];
+    if (HAS_BIAS) {
+#pragma unroll
+        for (int g = 0; g < (HAS_BIAS ? 4 : 1); ++g) {
+            const int ob = wave * 32 + 8 * g + 4 * kk;
+            bias4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && ob < O) bias4[g] = ld4(p.bias + ob);
+        }
+#pragma unroll
+        for (int g = 0; g < (HAS_BIAS ? 4 : 1); ++g) asm volatile("" : "+v"(bias4[g].x), "+v"(bias4[g].y), "+v"(bias4[g].z), "+v"(bias4[g].w));
+    }
     int64_t tile = blockIdx.x;
     if (PRO < 2) { if (tile < tiles) { issue(tile); commit(); } }
     else if (tile < tiles) load_bwd(tile);
@@ -251,8 +276,7 @@ lin_fused_kernel(const LinFParams p) {
         for (int g = 0; g < 4; ++g) {
             const int ob = wave * 32 + 8 * g + 4 * kk;
             if (ob < O) {                              // O % 4 == 0 (host): the 4 outputs of a group are in or out together
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) bb = ld4(p.bias + ob);
+                const float4 bb = HAS_BIAS ? bias4[HAS_BIAS ? g : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int m = 0; m < M; ++m)            // pitch = 4 (mod 8) floats -> 16-B LDS accesses, no conflicts
                     st4(xl + (m * 32 + c) * pitch + ob,

@@ -8,6 +8,7 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1, "linear_bn: bad N=%lld O=%d I=%d", (long long)d->N, d->O, d->I);
     KPGNN_REQUIRE(d->x && d->w && d->y, "linear_bn: NULL pointer");
     KPGNN_REQUIRE(d->pro >= 0 && d->pro <= 3 && d->epi >= 0 && d->epi <= 2, "linear_bn: bad pro=%d / epi=%d", d->pro, d->epi);
+    KPGNN_REQUIRE(d->pro < 2 || d->bias == nullptr, "linear_bn: the backward variants (pro %d) take no bias", d->pro);
     if (!lin_supported_width(d->I) || (d->O % 4) != 0 || d->O > 128)
         return fail(KPGNN_ELIMIT, "linear_bn: I=%d must be one of 32, 64, 96, 104, 128 and O=%d a multiple of 4 <= 128", d->I, d->O);
     uintptr_t al = (uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->bias | (uintptr_t)d->x2 | (uintptr_t)d->xt | (uintptr_t)d->e_x;

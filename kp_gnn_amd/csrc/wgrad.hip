@@ -229,6 +229,188 @@ int wgrad_launch(const WgPair& pp, int nprob, int O, int I, int grid, hipStream_
     return KPGNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged variant
+// The kernel above feeds the matrix cores straight from global memory with one dword per lane and operand: x is fetched
+// once per output strip (4x through L1) in 256-byte wave requests, and the launch sat at 35 % matrix-core occupancy whatever
+// was done to its latency.  Here a block stages 32 rows of dy and x in LDS with 16-byte loads (requested one
+// chunk ahead, held in registers across the MFMA phase) and every strip reads its operands from there: x crosses L1 once,
+// the optional transforms (BatchNorm + ReLU of x, ReLU mask of dy) are applied once per element on the way in.
+// Several problems that share N, O, I run SIDE BY SIDE on disjoint block ranges of one launch (the two Linears of an MLP;
+// the S column blocks of a jumping-knowledge projection, which also share dy): the slab keeps the size of a single problem's.
+constexpr int kW2Rows = 32;
+constexpr int kW2MaxProb = 16;
+
+struct Wg2Prob {
+    const float* dy; const float* x; const float* mask;
+    const float* xm; const float* xi; const float* xg; const float* xb;
+    int xrelu;
+    int64_t dys, xs, out_off, bias_off;      // offsets inside a slab row; bias_off < 0: this problem writes no bias gradient
+};
+struct Wg2Args {
+    int64_t N; const int32_t* n_dyn;
+    int O, I, nprob; int64_t ldw;
+    float* slab; int64_t slab_row;
+    Wg2Prob q[kW2MaxProb];
+};
+
+template <int TI>
+__global__ void __launch_bounds__(256, 2)
+wgrad2_kernel(const Wg2Args A) {
+    extern __shared__ __attribute__((aligned(16))) float w2[];
+    constexpr int R = kW2Rows;
+    const int O = A.O, I = A.I;
+    float* dyl = w2;                       // [R][O]
+    float* xl = w2 + R * O;                // [R][I]
+    float* coef = xl + R * I;              // [4][I]  (mean, invstd, gamma, beta of the x transform)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kk = lane >> 5, c = lane & 31;
+    const int nprob = A.nprob;
+    const int pi = (int)(blockIdx.x % nprob), slice = (int)(blockIdx.x / nprob), nslices = (int)(gridDim.x / nprob);
+    Wg2Prob q = A.q[0];                    // (uniform selects: a runtime index into the argument array would turn every use into
+#pragma unroll                             //  a scalar load from the kernel-argument segment)
+    for (int i = 1; i < kW2MaxProb; ++i)
+        if (pi == i) q = A.q[i];
+    const int64_t N = A.n_dyn ? (int64_t)min((int64_t)*A.n_dyn, A.N) : A.N;
+    const bool tr = q.xm != nullptr;
+    if (tr)
+        for (int i = tid; i < I; i += 256) { coef[i] = q.xm[i]; coef[I + i] = q.xi[i]; coef[2 * I + i] = q.xg[i]; coef[3 * I + i] = q.xb[i]; }
+    // this thread's float4 slots of the two tiles (fixed for the whole launch)
+    const int o4 = O >> 2, i4 = I >> 2;
+    int dy_row[4], dy_cg[4], x_row[TI], x_cg[TI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int e = tid + 256 * j; dy_row[j] = e < R * o4 ? e / o4 : -1; dy_cg[j] = e % o4; }
+#pragma unroll
+    for (int j = 0; j < TI; ++j) { const int e = tid + 256 * j; x_row[j] = e < R * i4 ? e / i4 : -1; x_cg[j] = e % i4; }
+    float4 pdy[4], pm[4], px[TI];
+    const bool has_mask = q.mask != nullptr;
+    // Loads are UNCONDITIONAL (rows beyond N and slots this thread does not own are clamped to a valid address and zeroed /
+    // skipped at commit time): a predicated load compiles to a divergent branch with an `s_waitcnt vmcnt(0)` at its join, which
+    // serialised the seven requests of a chunk into seven round trips.
+    const int64_t last = N - 1;            // (N >= 1)
+    auto issue = [&](int64_t ch) {
+        const int64_t r0 = ch * R;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = min(r0 + max(dy_row[j], 0), last);
+            pdy[j] = *reinterpret_cast<const float4*>(q.dy + r * q.dys + 4 * dy_cg[j]);
+            if (has_mask) pm[j] = *reinterpret_cast<const float4*>(q.mask + r * q.dys + 4 * dy_cg[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            const int64_t r = min(r0 + max(x_row[j], 0), last);
+            px[j] = *reinterpret_cast<const float4*>(q.x + r * q.xs + 4 * x_cg[j]);
+        }
+    };
+    auto commit = [&](int64_t ch) {
+        const int64_t r0 = ch * R;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = pdy[j];
+            if (has_mask) { v.x = pm[j].x > 0.f ? v.x : 0.f; v.y = pm[j].y > 0.f ? v.y : 0.f; v.z = pm[j].z > 0.f ? v.z : 0.f; v.w = pm[j].w > 0.f ? v.w : 0.f; }
+            if (r0 + dy_row[j] >= N) v = zero;
+            if (dy_row[j] >= 0) *reinterpret_cast<float4*>(dyl + dy_row[j] * O + 4 * dy_cg[j]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+            float4 v = px[j];
+            if (tr) {
+                const float4 m = *reinterpret_cast<const float4*>(coef + 4 * x_cg[j]), s = *reinterpret_cast<const float4*>(coef + I + 4 * x_cg[j]);
+                const float4 g = *reinterpret_cast<const float4*>(coef + 2 * I + 4 * x_cg[j]), b = *reinterpret_cast<const float4*>(coef + 3 * I + 4 * x_cg[j]);
+                v.x = fmaf((v.x - m.x) * s.x, g.x, b.x); v.y = fmaf((v.y - m.y) * s.y, g.y, b.y);
+                v.z = fmaf((v.z - m.z) * s.z, g.z, b.z); v.w = fmaf((v.w - m.w) * s.w, g.w, b.w);
+                if (q.xrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (r0 + x_row[j] >= N) v = zero;     // (rows beyond N must stay zero)
+            if (x_row[j] >= 0) *reinterpret_cast<float4*>(xl + x_row[j] * I + 4 * x_cg[j]) = v;
+        }
+    };
+    f32x16 acc[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    float bsum = 0.f;
+    const int o = wave * 32 + c;
+    const bool o_ok = o < O;
+    // (padded lanes read the last valid column: what they accumulate lands in rows / columns that are never stored)
+    const float* ap = dyl + kk * O + (o_ok ? o : O - 1);
+    const float* bp[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) bp[t] = xl + kk * I + min(t * 32 + c, I - 1);
+    const int64_t chunks = (N + R - 1) / R;
+    int64_t ch = slice;
+    if (tr) __syncthreads();
+    if (ch < chunks) { issue(ch); commit(ch); }
+    __syncthreads();
+    for (; ch < chunks; ch += nslices) {
+        const int64_t nx = ch + nslices;
+        const bool more = nx < chunks;
+        if (more) issue(nx);
+#pragma unroll
+        for (int p2 = 0; p2 < R / 2; ++p2) {
+            const float a = ap[2 * p2 * O];
+            bsum += a;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[t][2 * p2 * I], acc[t], 0, 0, 0);
+        }
+        __syncthreads();                              // every wave is done with this chunk's tiles
+        if (more) commit(nx);
+        __syncthreads();
+    }
+    bsum += __shfl_xor(bsum, 32);                     // the two k halves hold different rows of the same column
+    float* out = A.slab + (int64_t)slice * A.slab_row;
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+        const int i = t * 32 + c;
+        for (int v = 0; v < 16; ++v) {
+            const int orow = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+            if (orow < O && i < I) out[q.out_off + (int64_t)orow * A.ldw + i] = acc[t][v];
+        }
+    }
+    if (q.bias_off >= 0 && kk == 0 && o_ok) out[q.bias_off + o] = bsum;
+}
+
+bool wgrad2_ok(const kpgnn_wgrad_desc* d, const float* x) {
+    auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    return d->O % 4 == 0 && d->I % 4 == 0 && d->O <= 128 && d->I <= 256 && d->dy_stride % 4 == 0 && d->x_stride % 4 == 0 &&
+           al(d->dy) && al(x) && (!d->dy_mask || al(d->dy_mask));
+}
+
+Wg2Prob wgrad2_prob(const kpgnn_wgrad_desc* d, const float* x, int64_t out_off, int64_t bias_off) {
+    Wg2Prob q;
+    q.dy = d->dy; q.x = x; q.mask = d->dy_mask; q.xm = d->x_mean; q.xi = d->x_invstd; q.xg = d->x_gamma; q.xb = d->x_beta;
+    q.xrelu = d->x_relu; q.dys = d->dy_stride; q.xs = d->x_stride; q.out_off = out_off; q.bias_off = bias_off;
+    return q;
+}
+
+// slices (= slab rows) per problem: the problems share the chip's 2 x 256 block slots; >= 1 chunk of rows per slice
+int wgrad2_slices(int64_t N, int nprob) {
+    const int64_t chunks = (N + kW2Rows - 1) / kW2Rows;
+    int64_t s = kWgradBlocks / nprob;
+    if (s > chunks) s = chunks;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int wgrad2_launch(Wg2Args& A, int nslices, hipStream_t s) {
+    const int ti = (A.I + 31) / 32;
+    const size_t lds = sizeof(float) * ((size_t)kW2Rows * (A.O + A.I) + 4 * (size_t)A.I);
+    dim3 gr((unsigned)(nslices * A.nprob)), blk(256);
+#define KP_W2(T) hipLaunchKernelGGL((wgrad2_kernel<T>), gr, blk, lds, s, A)
+    switch (ti) {
+        case 1: KP_W2(1); break;
+        case 2: KP_W2(2); break;
+        case 3: KP_W2(3); break;
+        case 4: KP_W2(4); break;
+        case 5: KP_W2(5); break;
+        case 6: KP_W2(6); break;
+        case 7: KP_W2(7); break;
+        default: KP_W2(8); break;
+    }
+#undef KP_W2
+    KPGNN_LAUNCH_CHECK("wgrad2_kernel");
+    return KPGNN_OK;
+}
+
 }  // namespace
 }  // namespace kpgnn
 
@@ -245,11 +427,21 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= kpgnn_wgrad_workspace_bytes(d->O, d->I), "linear_wgrad: workspace too small");
     const int64_t nw = (int64_t)d->O * d->I;
     float* slab = (float*)d->workspace;
-    WgPair pp;
-    pp.q[0] = pp.q[1] = wgrad_params(d, slab, nw + d->O, 0);
-    const int grid = wgrad_blocks(d->N, d->O);
     hipStream_t s = (hipStream_t)stream;
-    rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
+    int grid;
+    if (wgrad2_ok(d, d->x)) {
+        Wg2Args A;
+        A.N = d->N; A.n_dyn = d->n_dyn; A.O = d->O; A.I = d->I; A.nprob = 1; A.ldw = d->I; A.slab = slab; A.slab_row = nw + d->O;
+        for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(d, d->x, 0, nw);
+        grid = wgrad2_slices(d->N, 1);
+        rc = wgrad2_launch(A, grid, s);
+    } else {
+        KPGNN_REQUIRE(!d->dy_mask && !d->n_dyn, "linear_wgrad: dy_mask / n_dyn need 16-B aligned operands with O %% 4 == I %% 4 == 0, O <= 128");
+        WgPair pp;
+        pp.q[0] = pp.q[1] = wgrad_params(d, slab, nw + d->O, 0);
+        grid = wgrad_blocks(d->N, d->O);
+        rc = wgrad_launch(pp, 1, d->O, d->I, grid, s);
+    }
     if (rc != KPGNN_OK) return rc;
     float* db = d->db ? d->db : slab + (size_t)kWgradBlocks * (nw + d->O);  // sink behind the slabs
     if (d->defer) {
@@ -272,12 +464,23 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
     KPGNN_REQUIRE(a->workspace && a->workspace_bytes >= 2 * kpgnn_wgrad_workspace_bytes(a->O, a->I), "linear_wgrad_pair: workspace too small");
     const int64_t nw = (int64_t)a->O * a->I, one = nw + a->O;
     float* slab = (float*)a->workspace;
-    WgPair pp;
-    pp.q[0] = wgrad_params(a, slab, 2 * one, 0);
-    pp.q[1] = wgrad_params(b, slab, 2 * one, one);
-    const int grid = wgrad_blocks(a->N, a->O);
     hipStream_t s = (hipStream_t)stream;
-    rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
+    int grid;
+    if (wgrad2_ok(a, a->x) && wgrad2_ok(b, b->x)) {
+        Wg2Args A;
+        A.N = a->N; A.n_dyn = a->n_dyn; A.O = a->O; A.I = a->I; A.nprob = 2; A.ldw = a->I; A.slab = slab; A.slab_row = 2 * one;
+        for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(a, a->x, 0, nw);
+        A.q[1] = wgrad2_prob(b, b->x, one, one + nw);
+        grid = wgrad2_slices(a->N, 2);
+        rc = wgrad2_launch(A, grid, s);
+    } else {
+        KPGNN_REQUIRE(!a->dy_mask && !b->dy_mask && !a->n_dyn, "linear_wgrad_pair: dy_mask / n_dyn need 16-B aligned operands");
+        WgPair pp;
+        pp.q[0] = wgrad_params(a, slab, 2 * one, 0);
+        pp.q[1] = wgrad_params(b, slab, 2 * one, one);
+        grid = wgrad_blocks(a->N, a->O);
+        rc = wgrad_launch(pp, 2, a->O, a->I, grid, s);
+    }
     if (rc != KPGNN_OK) return rc;
     if (a->defer) {
         kpgnn_reduce_job* j = a->defer;
@@ -289,6 +492,42 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
     return slab_reduce(slab, grid, 2 * one, a->dw, nw, a->db, a->O, b->dw, s, nw, b->db);
 }
 
+extern "C" size_t kpgnn_wgrad_group_workspace_bytes(int32_t O, int32_t I, int32_t group) {
+    if (O < 1 || I < 1 || group < 1 || group > kW2MaxProb) return 0;
+    return sizeof(float) * ((size_t)(kWgradBlocks / group) * ((size_t)O * I * group + O) + O);
+}
+
+extern "C" int kpgnn_linear_wgrad_group(const kpgnn_wgrad_desc* d, const float* const* x_group, int32_t group, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr && x_group != nullptr && group >= 1 && group <= kW2MaxProb, "linear_wgrad_group: bad arguments (1 <= group <= %d)", kW2MaxProb);
+    kpgnn_wgrad_desc probe = *d;
+    probe.x = x_group[0];
+    int rc = wgrad_check(&probe, "linear_wgrad_group");
+    if (rc != KPGNN_OK) return rc;
+    for (int l = 0; l < group; ++l)
+        if (!x_group[l] || !wgrad2_ok(d, x_group[l]))
+            return fail(KPGNN_ELIMIT, "linear_wgrad_group: needs 16-B aligned operands, O %% 4 == I %% 4 == 0, O <= 128, I <= 256");
+    KPGNN_REQUIRE(!d->x_mean, "linear_wgrad_group: no x transform");
+    KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= kpgnn_wgrad_group_workspace_bytes(d->O, d->I, group), "linear_wgrad_group: workspace too small");
+    const int64_t nw = (int64_t)d->O * d->I * group;
+    Wg2Args A;
+    A.N = d->N; A.n_dyn = d->n_dyn; A.O = d->O; A.I = d->I; A.nprob = group; A.ldw = (int64_t)d->I * group;
+    A.slab = (float*)d->workspace; A.slab_row = nw + d->O;
+    for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(d, x_group[i < group ? i : 0], (int64_t)(i < group ? i : 0) * d->I, i == 0 ? nw : -1);
+    const int grid = wgrad2_slices(d->N, group);
+    hipStream_t s = (hipStream_t)stream;
+    rc = wgrad2_launch(A, grid, s);
+    if (rc != KPGNN_OK) return rc;
+    float* db = d->db ? d->db : A.slab + (size_t)grid * A.slab_row;     // sink behind the slab rows
+    if (d->defer) {
+        kpgnn_reduce_job* j = d->defer;
+        j->slab = A.slab; j->nslab = grid; j->elems = nw + d->O;
+        j->out[0] = d->dw; j->n_out[0] = nw; j->out[1] = db; j->n_out[1] = d->O;
+        j->out[2] = j->out[3] = nullptr; j->n_out[2] = j->n_out[3] = 0;
+        return KPGNN_OK;
+    }
+    return slab_reduce(A.slab, grid, nw + d->O, d->dw, nw, db, d->O, nullptr, s);
+}
+
 // ------------------------------------------------------------------------------------------------ y = x W^T + b
 namespace kpgnn {
 namespace {
@@ -296,6 +535,7 @@ namespace {
 struct LinParams {
     int64_t N; int O, I, pitch, ypitch, wt;
     const float* x; int64_t xs;
+    const float* xmask; const int32_t* n_dyn;   // optional ReLU mask of x (same layout), optional live-row count
     const float* w; const float* bias;
     float* y; int64_t ys;
     int yb; int64_t ybs;   // wide kernel: output column o lands in block o / yb at column o % yb; blocks are ybs floats apart (yb == O: plain rows)
@@ -314,16 +554,23 @@ linear_wide_kernel(const LinParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 5, c = lane & 31;
     const int O = p.O, pitch = p.pitch;
-    const int64_t tiles = (p.N + ROWS - 1) / ROWS;
+    const int64_t N = p.n_dyn ? (int64_t)min((int64_t)*p.n_dyn, p.N) : p.N;
+    const int64_t tiles = (N + ROWS - 1) / ROWS;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         __syncthreads();                               // previous tile fully consumed
         {   // x tile -> LDS (no register double-buffer: the eight output chunks dwarf this load)
             const int64_t r0 = tile * ROWS;
-            const int lim = (int)(p.N - r0 < ROWS ? p.N - r0 : ROWS) * IC;
+            const int lim = (int)(N - r0 < ROWS ? N - r0 : ROWS) * IC;
             const float* base = p.x + r0 * p.xs;
             for (int e = 4 * tid; e < ROWS * IC; e += 4 * 256) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < lim) v = *reinterpret_cast<const float4*>(base + e);
+                if (e < lim) {
+                    v = *reinterpret_cast<const float4*>(base + e);
+                    if (p.xmask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.xmask + r0 * p.xs + e);
+                        if (mk.x <= 0.f) v.x = 0.f; if (mk.y <= 0.f) v.y = 0.f; if (mk.z <= 0.f) v.z = 0.f; if (mk.w <= 0.f) v.w = 0.f;
+                    }
+                }
                 *reinterpret_cast<float4*>(xl + (e / IC) * pitch + (e % IC)) = v;
             }
         }
@@ -372,7 +619,7 @@ linear_wide_kernel(const LinParams p) {
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const int64_t r = r0 + m * 32 + c;
-                        if (r < p.N)
+                        if (r < N)
                             *reinterpret_cast<float4*>(p.y + (int64_t)(ob / p.yb) * p.ybs + r * p.ys + (ob % p.yb)) =
                                 make_float4(acc[m][4 * g] + bb.x, acc[m][4 * g + 1] + bb.y, acc[m][4 * g + 2] + bb.z, acc[m][4 * g + 3] + bb.w);
                     }
@@ -399,6 +646,8 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
         (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
         return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
+    if (d->O <= 128 && (d->x_mask || d->n_dyn)) return fail(KPGNN_ELIMIT, "linear_fwd: x_mask / n_dyn are implemented for O > 128");
+    if (d->x_mask && (((uintptr_t)d->x_mask) & 15) != 0) return fail(KPGNN_ELIMIT, "linear_fwd: x_mask must be 16-B aligned");
     if (d->O <= 128) {                                  // the plain variant of the fused kernel (lin_fused.h)
         kpgnn_linear_bn_desc f = {};
         f.N = d->N; f.O = d->O; f.I = d->I; f.x = d->x; f.w = d->w; f.bias = d->bias; f.y = d->y; f.w_transposed = d->w_transposed;
@@ -411,6 +660,7 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
     const int rowp = d->I + ((4 - d->I % 8) + 8) % 8;   // pitch = 4 (mod 8) floats: 16-B aligned rows, conflict-free 16-B accesses
     p.pitch = rowp; p.ypitch = rowp;
     p.x = d->x; p.xs = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y; p.ys = d->y_stride;
+    p.xmask = d->x_mask; p.n_dyn = d->n_dyn;
     p.yb = blocked ? d->y_block_cols : d->O; p.ybs = blocked ? d->y_block_stride : 0;
     // rows per tile = 32 * m, m in 1..3, the smallest that makes the launch one round over two blocks per CU
     const int64_t slots = (int64_t)device_facts().cu_count * 2;

@@ -419,17 +419,49 @@ def mlp_linear_bn_relu_x2(mlp, h, emit_out_stats=False, post_norm=None):
 
 
 # ------------------------------------------------------------------------------------ jumping-knowledge projection
+def _jk_native_ok(weight, bias, states):
+    """Shapes the grouped-K kernels take: S <= 16 contiguous fp32 [N,H] states of one width H in {32, 64, 96, 104, 128},
+    O <= 128 with O % 4 == 0, S * H > 128 (the blocked input-gradient kernel), 16-B aligned operands."""
+    S = len(states)
+    N, H = states[0].shape
+    O = weight.shape[0]
+    return (2 <= S <= 16 and H in _LIN_WIDTHS and O % 4 == 0 and O in (32, 64, 104, 128) and S * H > 128 and N >= 1
+            and tuple(weight.shape) == (O, S * H) and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+            and (bias is None or (bias.is_contiguous() and bias.data_ptr() % 16 == 0))
+            and all(st.shape == (N, H) and st.dtype == torch.float32 and st.is_contiguous() and st.data_ptr() % 16 == 0 for st in states))
+
+
 class JKConcatLinear(torch.autograd.Function):
     """relu(cat(states, dim=1) W^T + b): the bodies' jumping-knowledge projection (models/GNNs.py:216-218, output_proj).
-    Forward is the reference's concat + one GEMM.  Backward: the input gradient dY W of all S states comes out of ONE
-    launch as S contiguous [N,H] matrices (kpgnn_linear_fwd with a blocked output: 118 us against the BLAS library's
-    146 us for [47k,104] x [104,936]), and a state whose gradient is being collected in a cell (ops.state_cell: GNNPlus'
-    hop-slot history) gets its matrix PARKED there - the layers' gather kernels and the norms' residual branches then
-    add into it in place and the state's last reader hands autograd the total, instead of autograd summing S + 2
-    strided tensors per state (36 adds of ~20 MB per step at K = L = 8)."""
+    Native path (kpgnn_linear_group_fwd / kpgnn_linear_fwd / kpgnn_linear_wgrad_group): the concatenation is never made - the
+    GEMM's K-loop runs over the state pointers; backward reads the ReLU mask from the saved output while it loads dy
+    (no masked copy), the input gradient of all S states comes out of ONE launch as S contiguous [N,H] matrices, and the
+    weight gradient's S column blocks run side by side in one launch.  A state whose gradient is being collected in a cell
+    (ops.state_cell: GNNPlus' hop-slot history) gets its matrix PARKED there - the layers' gather kernels and the norms'
+    residual branches then add into it in place and the state's last reader hands autograd the total, instead of autograd
+    summing S + 2 strided tensors per state (36 adds of ~20 MB per step at K = L = 8).
+    Shapes outside the kernels' limits keep the reference's concat + library GEMM."""
 
     @staticmethod
     def forward(ctx, weight, bias, *states):
+        ctx.native = _jk_native_ok(weight, bias, states)
+        ctx.cells = [getattr(st, "_kp_slot_cell", None) for st in states]
+        ctx.widths = [st.shape[1] for st in states]
+        ctx.has_bias = bias is not None
+        if ctx.native:
+            lib = _lib.load()
+            N, H = states[0].shape
+            O = weight.shape[0]
+            y = torch.empty((N, O), dtype=torch.float32, device=weight.device)
+            d = _lib.LinearGroupDesc()
+            d.N, d.O, d.I, d.group = N, O, H, len(states)
+            for l, st in enumerate(states):
+                d.x[l] = st.data_ptr()
+            d.x_stride, d.w, d.bias, d.y, d.relu = H, weight.data_ptr(), _ptr(bias), y.data_ptr(), 1
+            with torch.cuda.device(weight.device):
+                _lib.check(lib.kpgnn_linear_group_fwd(ctypes.byref(d), _stream(y)), "kpgnn_linear_group_fwd")
+            ctx.save_for_backward(weight, y, *states)
+            return y
         rep = torch.cat(states, dim=1)
         if bias is not None and hasattr(torch, "_addmm_activation"):
             # the library GEMM with the bias + ReLU epilogue fused (bitwise the same as addmm + relu_; 117 vs 128 us at [47k, 936])
@@ -438,35 +470,57 @@ class JKConcatLinear(torch.autograd.Function):
             y = torch.addmm(bias, rep, weight.t()) if bias is not None else rep @ weight.t()
             y.relu_()
         ctx.save_for_backward(weight, rep, y)
-        ctx.cells = [getattr(st, "_kp_slot_cell", None) for st in states]
-        ctx.widths = [st.shape[1] for st in states]
-        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        weight, rep, y = ctx.saved_tensors
         S, H = len(ctx.widths), ctx.widths[0]
-        N, O = y.shape
-        dym = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
-        dw = dym.t() @ rep if ctx.needs_input_grad[0] else None
-        db = dym.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
-        parts = None
-        if (all(w == H for w in ctx.widths) and S * H > 128 and H % 4 == 0 and O in (32, 64, 104, 128) and weight.is_contiguous()
-                and dym.data_ptr() % 16 == 0):
-            lib = _lib.load()
-            G = torch.empty((S, N, H), dtype=torch.float32, device=dy.device)
-            d = _lib.LinearDesc()
-            d.N, d.O, d.I = N, S * H, O
-            d.x, d.x_stride, d.w, d.y, d.y_stride = dym.data_ptr(), O, weight.data_ptr(), G.data_ptr(), H
-            d.w_transposed, d.y_block_cols, d.y_block_stride = 1, H, N * H
-            with torch.cuda.device(dy.device):
-                rc = lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(dym))
-            if rc == 0:
-                parts = [G[l] for l in range(S)]
-            elif rc != -3:
-                _lib.check(rc, "kpgnn_linear_fwd")
-        if parts is None:
+        lib = _lib.load()
+        dy = dy.contiguous()
+        if ctx.native and dy.data_ptr() % 16 == 0:
+            weight, y, *states = ctx.saved_tensors
+            N, O = y.shape
+            dev = dy.device
+            dw = db = None
+            with torch.cuda.device(dev):
+                G = torch.empty((S, N, H), dtype=torch.float32, device=dev)
+                d = _lib.LinearDesc()
+                d.N, d.O, d.I = N, S * H, O
+                d.x, d.x_stride, d.w, d.y, d.y_stride = dy.data_ptr(), O, weight.data_ptr(), G.data_ptr(), H
+                d.w_transposed, d.y_block_cols, d.y_block_stride = 1, H, N * H
+                d.x_mask = y.data_ptr()                       # dL/d(pre-activation) = dy where the saved output is > 0
+                _lib.check(lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(dy)), "kpgnn_linear_fwd")
+                if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
+                    from . import ops
+                    dw = torch.empty((O, S * H), dtype=torch.float32, device=dev)
+                    db = torch.empty((O,), dtype=torch.float32, device=dev)
+                    nb = int(lib.kpgnn_wgrad_group_workspace_bytes(O, H, S))
+                    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    q = _lib.WgradDesc()
+                    q.N, q.O, q.I = N, O, H
+                    q.dy, q.dy_stride, q.x, q.x_stride = dy.data_ptr(), O, states[0].data_ptr(), H
+                    q.dy_mask = y.data_ptr()
+                    q.dw, q.db, q.workspace, q.workspace_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb
+                    xs = (ctypes.c_void_p * S)(*[st.data_ptr() for st in states])
+                    job = ops.defer_reduce_job()           # (inside ops.deferred_reductions(): the reduce rides with a later launch)
+                    if job is not None:
+                        q.defer = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
+                    _lib.check(lib.kpgnn_linear_wgrad_group(ctypes.byref(q), xs, S, _stream(dy)), "kpgnn_linear_wgrad_group")
+                    if job is not None:
+                        ops.queue_reduce_job(job, (ws, dw, db))
+            parts = [G[l] for l in range(S)]
+            if not ctx.has_bias:
+                db = None
+        else:
+            if ctx.native:
+                weight, y, *states = ctx.saved_tensors
+                rep = torch.cat(states, dim=1)
+            else:
+                weight, rep, y = ctx.saved_tensors
+            N, O = y.shape
+            dym = torch.ops.aten.threshold_backward(dy, y, 0.0)
+            dw = dym.t() @ rep if ctx.needs_input_grad[0] else None
+            db = dym.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
             G = dym @ weight
             parts, c0 = [], 0
             for w in ctx.widths:

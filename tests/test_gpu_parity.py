@@ -705,6 +705,67 @@ def test_linear_wgrad_pair_and_x_transform():
     _close(db[1], dy2.sum(0), "db1", rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("N,H,S,O", [(4099, 104, 9, 104), (300, 32, 5, 64), (1000, 104, 2, 104), (2050, 64, 16, 128), (513, 96, 3, 32)])
+def test_jk_projection_native_vs_torch(N, H, S, O):
+    """The bodies' jumping-knowledge projection relu(cat(h_list) W^T + b) (models/GNNs.py:216-218, :455-457) on the grouped-K
+    kernels - kpgnn_linear_group_fwd (K-loop over the state pointers, no concat), kpgnn_linear_fwd with the ReLU mask read on
+    load, kpgnn_linear_wgrad_group (S column blocks side by side) - against the reference's op sequence on the CPU: output,
+    every state's gradient, dW, db.  Pre-activations within rounding of the ReLU kink are excluded from the comparison by
+    construction: the CPU side applies the mask the GPU forward produced."""
+    from kp_gnn_amd.ops_dense import JKConcatLinear, _jk_native_ok
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + S)
+    states = [torch.randn(N, H, generator=g) * (1 + 0.1 * l) for l in range(S)]
+    w = torch.randn(O, S * H, generator=g) * 0.05
+    b = torch.randn(O, generator=g) * 0.1
+    gy = torch.randn(N, O, generator=g) * (1 + torch.arange(O) * 0.01)
+    sd = [t.clone().to(dev).requires_grad_(True) for t in states]
+    wd, bd = w.clone().to(dev).requires_grad_(True), b.clone().to(dev).requires_grad_(True)
+    assert _jk_native_ok(wd, bd, sd)
+    y = JKConcatLinear.apply(wd, bd, *sd)
+    (y * gy.to(dev)).sum().backward()
+    sr = [t.clone().requires_grad_(True) for t in states]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = torch.nn.functional.linear(torch.cat(sr, dim=1), wr, br)
+    _close(y, torch.relu(pre.detach()), "y", rtol=2e-4, atol=2e-5)
+    mask = (y.detach().cpu() > 0).to(pre.dtype)
+    ((pre * mask) * gy).sum().backward()
+    _close(wd.grad, wr.grad, "dW", rtol=2e-4, atol=2e-5)
+    _close(bd.grad, br.grad, "db", rtol=2e-4, atol=2e-5)
+    for l in range(S):
+        _close(sd[l].grad, sr[l].grad, f"dstate{l}", rtol=2e-4, atol=2e-5)
+    # without bias, and a second call gives the same bits (fixed summation order)
+    wd2 = w.clone().to(dev).requires_grad_(True)
+    y2 = JKConcatLinear.apply(wd2, None, *[t.detach() for t in sd])
+    (y2 * gy.to(dev)).sum().backward()
+    wd3 = w.clone().to(dev).requires_grad_(True)
+    (JKConcatLinear.apply(wd3, None, *[t.detach() for t in sd]) * gy.to(dev)).sum().backward()
+    assert torch.equal(wd2.grad, wd3.grad)
+
+
+def test_linear_wgrad_relu_mask_on_load():
+    """kpgnn_linear_wgrad with dy_mask: dW = (dy * [mask > 0])^T x without the masked copy."""
+    import ctypes
+    from kp_gnn_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    N, O, I = 2777, 104, 64
+    dy, x, m = torch.randn(N, O, generator=g), torch.randn(N, I, generator=g), torch.randn(N, O, generator=g)
+    d_dy, d_x, d_m = dy.to(dev), x.to(dev), m.to(dev)
+    dw, db = torch.empty(O, I, device=dev), torch.empty(O, device=dev)
+    nb = int(lib.kpgnn_wgrad_workspace_bytes(O, I))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    q = _lib.WgradDesc()
+    q.N, q.O, q.I = N, O, I
+    q.dy, q.dy_stride, q.x, q.x_stride, q.dy_mask = d_dy.data_ptr(), O, d_x.data_ptr(), I, d_m.data_ptr()
+    q.dw, q.db, q.workspace, q.workspace_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb
+    _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(q), torch.cuda.current_stream().cuda_stream), "kpgnn_linear_wgrad")
+    dym = dy * (m > 0)
+    _close(dw, dym.t() @ x, "dw", rtol=2e-4, atol=2e-5)
+    _close(db, dym.sum(0), "db", rtol=2e-4, atol=2e-5)
+
+
 def test_kgin_layer_matches_reference_goldens(golden_dir):
     """run_simulation.py's mask-only KGINConv (config 4) on the HIP path against vectors produced by the reference's own
     class (ast-extracted from the script, tests/golden/make_golden.py): output, input gradient, parameter gradients,
