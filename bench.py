@@ -383,6 +383,37 @@ def main():
         train_step(args, model, batches[i % len(batches)], opt, flat_grad, world)
     torch.cuda.synchronize()
     graphs = None
+    static = static_graph = None
+    if args.fresh_batches and not args.no_graph and args.train:
+        # ONE hipGraph for every batch: capacity-shaped static buffers refilled in place by kpgnn_collate, the live node count on
+        # the device (dataset.StaticBatch, ops.dynamic_rows).  The graph holds the collate launches, forward and backward.
+        from kp_gnn_amd._lib import KpgnnError
+        static = dataset.static_batch(args.batch)
+        try:
+            with static.dynamic():
+                for _ in range(2):
+                    static.stage(sampler())
+                    static.launch_collate()
+                    train_step(args, model, static.batch, opt, flat_grad, world)
+                torch.cuda.synchronize()
+                static.stage(sampler())
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    static.launch_collate()
+                    fwd_bwd(args, model, static.batch, flat_grad)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    static.launch_collate()
+                    out_static = fwd_bwd(args, model, static.batch, flat_grad)
+                static_graph = (g, out_static, False)
+        except KpgnnError as e:        # a configuration without dynamic-row kernels: exact-shape batches, eager launches
+            if rank == 0:
+                log(f"static-shape graph not available for this configuration ({e}); --fresh-batches runs eagerly")
+            static = static_graph = None
     if not args.no_graph and not args.fresh_batches:
         # (a capture failure is an error, not a silent downgrade to eager launches: --no-graph asks for those)
         graphs = capture_graphs(args, model, batches, flat_grad, opt if (args.train and world == 1 and args.adam_in_graph) else None)
@@ -391,11 +422,22 @@ def main():
         torch.cuda.synchronize()
     if rank == 0:
         log(f"{args.warmup} warm-up steps done; launch mode: {'hipGraph replay' if graphs else 'eager'}")
+    overflow_steps = 0
+    if args.fresh_batches:
+        from kp_gnn_amd.dataset import CapacityError
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if sampler is not None:        # a batch no step has seen: collated from the resident dataset, here, in the timed region
-            out_t = train_step(args, model, dataset.collate(sampler()), opt, flat_grad, world)
+            ids = sampler()
+            if static_graph is not None:
+                try:
+                    static.stage(ids)      # 16 KB of header to the device; the collate kernels are nodes of the graph
+                    out_t = train_step(args, model, static.batch, opt, flat_grad, world, static_graph)
+                    continue
+                except CapacityError:      # (a batch beyond the static capacity: exact shapes, eager launches)
+                    overflow_steps += 1
+            out_t = train_step(args, model, dataset.collate(ids), opt, flat_grad, world)
             continue
         j = i % len(batches)
         out_t = train_step(args, model, batches[j], opt, flat_grad, world, graphs[j] if graphs else None)
@@ -439,7 +481,10 @@ def main():
                        "graphs_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
                        "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.csr.E),
                        "active_pairs_per_batch": int(b0.csr.A),
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay of fwd+bwd" if graphs else "eager",
+                       "parallelism": f"dp{world}",
+                       "launch": ("hipGraph replay of collate+fwd+bwd: ONE static-shape graph for all batches (capacity "
+                                  f"{static.N_cap} nodes, live count on the device; {overflow_steps} eager overflow steps)") if static_graph
+                       else ("hipGraph replay of fwd+bwd" if graphs else "eager"),
                        "batches": (f"fresh: every step collates a new shuffled subset of a resident {args.dataset_graphs}-graph dataset "
                                    "(kpgnn_collate inside the timed region)") if args.fresh_batches
                        else f"{args.num_batches} pre-staged batches cycled",

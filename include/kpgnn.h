@@ -95,7 +95,10 @@ int kpgnn_tile_pack_filter(const int32_t* tile_ptr, const uint32_t* tile_pack, i
  * where kpgnn_tile_pack_filter takes three per k).  out_ptr int32[num_prefix][num_tiles+1], out_pack uint32[num_prefix][
  * pack_stride] (pack_stride >= tile_ptr[num_tiles]), scratch int32[num_prefix][num_tiles]. */
 int kpgnn_tile_pack_prefixes(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t num_prefix,
-                             int64_t pack_stride, int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch, kpgnn_stream_t stream);
+                             int64_t pack_stride, int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch,
+                             const int32_t* n_dyn, int32_t nodes_per_tile, kpgnn_stream_t stream);
+/* (n_dyn: optional device int32[1] live NODE count - num_tiles is then a capacity and the tiles beyond
+ *  ceil(*n_dyn / nodes_per_tile) count as empty; NULL: all num_tiles tiles are live) */
 
 /* ------------------------------------------------------------------------------------------------
  * Dataset-resident K-hop CSR + per-step collate (device).  Replaces the reference's storage / batching pair:
@@ -128,9 +131,9 @@ typedef struct kpgnn_row_gather { const void* src; void* dst; int32_t row_bytes;
 typedef struct kpgnn_collate_desc {
     kpgnn_dataset_view ds;
     int32_t B;                  /* graphs in the batch */
-    int32_t N;                  /* its nodes, pairs and entries: sums of per-graph counts the host keeps (launch sizes;  */
-    int64_t A;                  /*   the kernels themselves read them from the header)                                  */
-    int64_t n_ent;
+    int32_t N;                  /* its nodes, pairs and entries: sums of per-graph counts the host keeps.  They size the   */
+    int64_t A;                  /*   LAUNCHES only - the kernels read the real counts from the header - so they may be     */
+    int64_t n_ent;              /*   CAPACITIES of static buffers: one captured call then collates any batch that fits.   */
     /* device int32[4B+3]: ids[B] (dataset graph of batch slot b) | node_base[B+1] | pair_base[B+1] | ent_base[B+1], the three
      * exclusive prefix sums of the chosen graphs' node / pair / entry counts (last element = N / A / n_ent) */
     const int32_t* hdr;
@@ -255,6 +258,7 @@ typedef struct kpgnn_agg_fwd_desc {
     /* KPGNN_STORE_*: with BF16 the x_slot rows (storage) and pre (storage) are bf16 - pass them through these float
      * pointers; x_sn counts ELEMENTS. */
     int32_t storage;
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);
@@ -287,6 +291,7 @@ typedef struct kpgnn_agg_bwd_desc {
      * norm's residual branch also read collects its whole gradient in one buffer (K <= 32). */
     uint32_t accumulate_mask;
     int32_t storage;            /* KPGNN_STORE_*: with BF16, g (storage) holds bf16 rows; g_sn / g_sk count elements */
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_agg_bwd_desc;
 
 int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t stream);
@@ -358,6 +363,7 @@ typedef struct kpgnn_table_grad_desc {
     int32_t accumulate_dict;
     /* Optional (host pointer): one deferred reduction of an earlier call, added up by this call's finishing launch. */
     const kpgnn_reduce_job* pending;
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,
@@ -394,6 +400,7 @@ typedef struct kpgnn_dict_grad_desc {
      * instead of being accumulated node by node - exact for ANY choice (out-of-range values are read as 0), and 3-4x less
      * work when it is the hop's most frequent id (one id covers 82-99.9 % of the nodes of a hop in a molecule batch). */
     const int32_t* dominant;
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_dict_grad_desc;
 
 size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t n_dict);
@@ -455,6 +462,7 @@ typedef struct kpgnn_tgs_desc {
     int64_t gout_stride;
     float* gtable;              /* device [R, D] contiguous, OVERWRITTEN (backward; no atomics: bitwise reproducible) */
     void* workspace; size_t workspace_bytes;   /* backward: >= kpgnn_table_gather_sum_bwd_workspace_bytes(M, D, R) */
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_tgs_desc;
 
 int kpgnn_table_gather_sum_fwd(const kpgnn_tgs_desc* d, kpgnn_stream_t stream);
@@ -500,6 +508,7 @@ typedef struct kpgnn_bn_desc {
     float outer_eps, outer_momentum;
     float* outer_running_mean; float* outer_running_var; int64_t* outer_num_batches_tracked;
     float* outer_mean; float* outer_invstd;
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_bn_desc;
 
 typedef struct kpgnn_bn_bwd_desc {
@@ -520,6 +529,7 @@ typedef struct kpgnn_bn_bwd_desc {
      * 4 * kpgnn_stat_slot_bytes(C) (eight column sums, see bn.hip) and is consumed by kpgnn_linear_bn with pro = 3, which
      * applies both norms' backward while it loads its tile.  residual_grad (if set) still receives += dz. */
     const float* outer_mean; const float* outer_invstd;
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_bn_bwd_desc;
 
 int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream);
@@ -605,7 +615,7 @@ typedef struct kpgnn_linear_desc {
     int32_t y_block_cols; int64_t y_block_stride;
     /* Optional (O > 128 only) ReLU mask of x on load (device [N,I], rows x_stride apart): x' = x where x_mask > 0, else 0. */
     const float* x_mask;
-    const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N), as in kpgnn_wgrad_desc; O > 128 only */
+    const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N), as in kpgnn_wgrad_desc */
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
@@ -661,6 +671,7 @@ typedef struct kpgnn_linear_bn_desc {
     double* out_slot;
     const float* e_x; const float* e_mean; const float* e_invstd; const float* e_gamma; const float* e_beta;
     const float* o_mean; const float* o_invstd; const float* o_gamma; float* o_dgamma; float* o_dbeta;   /* pro 3 */
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_linear_bn_desc;
 
 int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t stream);
@@ -680,6 +691,7 @@ typedef struct kpgnn_pool_desc {
     float* out;                 /* device [G,D] contiguous (forward) */
     const float* gout;          /* device [G,D] contiguous (backward) */
     float* gx; int64_t gx_stride;          /* device [N,D] (backward, overwritten) */
+    const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
 } kpgnn_pool_desc;
 
 int kpgnn_segment_pool_fwd(const kpgnn_pool_desc* d, kpgnn_stream_t stream);

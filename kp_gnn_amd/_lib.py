@@ -28,6 +28,7 @@ class AggFwdDesc(ctypes.Structure):
         ("pre", c_vp), ("theta", c_vp), ("hout", c_vp), ("xbias", c_vp),
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp), ("storage", c_i32),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -41,6 +42,7 @@ class AggBwdDesc(ctypes.Structure):
         ("gx", c_vp), ("gx_sn", c_i64), ("gx_sk", c_i64),
         ("gtable0", c_vp), ("gtablek", c_vp),
         ("gx_slot", c_vp * 16), ("accumulate_mask", ctypes.c_uint32), ("storage", c_i32),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -60,6 +62,7 @@ class TableGradDesc(ctypes.Structure):
         ("fuse_g", c_vp), ("fuse_gtheta", c_vp), ("fuse_alphas", c_vp), ("fuse_galphas", c_vp),
         ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t), ("accumulate_dict", c_i32),
         ("pending", c_vp),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -68,6 +71,7 @@ class DictGradDesc(ctypes.Structure):
         ("N", c_i32), ("K", c_i32), ("D", c_i32), ("n_dict", c_i32),
         ("uid", c_vp), ("uid_stride", c_i64), ("theta", c_vp), ("gh", c_vp), ("gdict", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("defer_reduce", c_i32), ("dominant", c_vp),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -94,6 +98,7 @@ class BnDesc(ctypes.Structure):
         ("outer_gamma", c_vp), ("outer_beta", c_vp), ("outer_eps", ctypes.c_float), ("outer_momentum", ctypes.c_float),
         ("outer_running_mean", c_vp), ("outer_running_var", c_vp), ("outer_num_batches_tracked", c_vp),
         ("outer_mean", c_vp), ("outer_invstd", c_vp),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -105,6 +110,7 @@ class BnBwdDesc(ctypes.Structure):
         ("dx", c_vp), ("dx_stride", c_i64), ("dgamma", c_vp), ("dbeta", c_vp),
         ("stat_slot", c_vp), ("reduce_only", c_i32), ("residual_grad", c_vp), ("rg_stride", c_i64),
         ("outer_mean", c_vp), ("outer_invstd", c_vp),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -135,6 +141,7 @@ class LinearBnDesc(ctypes.Structure):
         ("out_slot", c_vp),
         ("e_x", c_vp), ("e_mean", c_vp), ("e_invstd", c_vp), ("e_gamma", c_vp), ("e_beta", c_vp),
         ("o_mean", c_vp), ("o_invstd", c_vp), ("o_gamma", c_vp), ("o_dgamma", c_vp), ("o_dbeta", c_vp),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -177,6 +184,7 @@ class TgsDesc(ctypes.Structure):
         ("idx", c_vp), ("col_offset", c_vp), ("table", c_vp), ("bias", c_vp),
         ("out", c_vp), ("out_stride", c_i64), ("gout", c_vp), ("gout_stride", c_i64), ("gtable", c_vp),
         ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -196,6 +204,7 @@ class PoolDesc(ctypes.Structure):
         ("N", c_i64), ("G", c_i32), ("D", c_i32), ("mode", c_i32),
         ("graph_ptr", c_vp), ("batch", c_vp), ("x", c_vp), ("x_stride", c_i64), ("out", c_vp),
         ("gout", c_vp), ("gx", c_vp), ("gx_stride", c_i64),
+        ("n_dyn", c_vp),
     ]
 
 
@@ -243,7 +252,7 @@ SIGNATURES = {
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "kpgnn_tile_pack_prefixes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "kpgnn_tile_pack_prefixes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "kpgnn_collate": (ctypes.c_int, [ctypes.POINTER(CollateDesc), c_vp]),
     "kpgnn_regression_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,

@@ -65,6 +65,7 @@ __device__ __forceinline__ float gelu_exact(float x) {  // F.gelu(approximate='n
 }
 
 struct FwdParams {
+    const int32_t* n_dyn;
     int N, K, D, K_csr, n_code0, n_codek, mode, combine, bf;
     const int32_t* rowptr;
     const int32_t* col;
@@ -95,6 +96,8 @@ struct FwdParams {
 template <int VEC, int G, bool GCN, int TAB, bool FAST = false, bool BF = false>
 __global__ void __launch_bounds__(kBlock, FAST ? 5 : 4)
 agg_fwd_kernel(const FwdParams p) {
+    // (a local: writing to the by-value argument would move the whole struct - pointer arrays indexed at run time - to scratch)
+    const int N_live = live_rows(p.N, p.n_dyn);
     const int MODE = FAST ? (int)KPGNN_MODE_GINPLUS : p.mode;
     const bool COMBINE = FAST ? true : p.combine != 0;
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
@@ -146,7 +149,7 @@ agg_fwd_kernel(const FwdParams p) {
     const int c0 = sl * VEC;
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
-    const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+    const int64_t num_tiles = ((int64_t)N_live + NODES - 1) / NODES;
     constexpr uint32_t XB = BF ? 2u : 4u;                       // bytes per stored element of a gathered row
     const uint32_t xrow_b = (uint32_t)p.x_sn * XB, trow_b = (uint32_t)D * 4u;   // (host: N * x_sn * 4 < 2^32)
     const uint32_t lane_b = col_ok ? (uint32_t)c0 * 4u : 0u;   // idle lanes re-read column 0 and are dropped below
@@ -158,7 +161,7 @@ agg_fwd_kernel(const FwdParams p) {
     //  measured slower: 134 us vs 109 us per launch at N = 47k, its 120 VGPRs cost a wave per SIMD.)
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t i = w.cur * NODES + sg;
-        if (i >= p.N) continue;             // whole sub-group leaves together
+        if (i >= N_live) continue;          // whole sub-group leaves together
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
         // The waves of this kernel sit in s_waitcnt 85 % of their cycles (PMC, profiles/r01): per hop there were three
@@ -356,6 +359,7 @@ agg_fwd_kernel(const FwdParams p) {
 }
 
 struct BwdParams {
+    const int32_t* n_dyn;
     int N, K, D, K_csr, n_code0, n_codek, mode, bf;
     const int32_t* rowptr;
     const int32_t* col;
@@ -378,6 +382,7 @@ struct BwdParams {
 template <int VEC, int G, bool GCN, int TAB, bool BF = false, bool GXACC = false>
 __global__ void __launch_bounds__(kBlock, 6)
 agg_bwd_kernel(const BwdParams p) {
+    const int N_live = live_rows(p.N, p.n_dyn);
     const int MODE = p.mode;
     extern __shared__ __attribute__((aligned(16))) float lds_gt[];
     const int D = p.D;
@@ -397,14 +402,14 @@ agg_bwd_kernel(const BwdParams p) {
     const int c0 = sl * VEC;
     const bool col_ok = c0 < D;
     const float eps1 = 1.0f + (p.eps ? p.eps[0] : 0.0f);
-    const int64_t num_tiles = ((int64_t)p.N + NODES - 1) / NODES;
+    const int64_t num_tiles = ((int64_t)N_live + NODES - 1) / NODES;
     constexpr uint32_t GB = BF ? 2u : 4u;                       // bytes per stored element of g
     const uint32_t grow_b = (uint32_t)p.g_sn * GB;              // (host: N * g_sn * 4 < 2^32)
     const uint32_t lane_b = col_ok ? (uint32_t)c0 * GB : 0u;   // idle lanes re-read column 0 and are dropped below
 
     for (XcdTileWalk w(num_tiles); w.valid(); w.next()) {
         const int64_t j = w.cur * NODES + sg;
-        if (j >= p.N) continue;
+        if (j >= N_live) continue;
         const int32_t* rp = p.rowptr + j * p.K_csr;
         // (as in the forward: row pointers and the node's whole pair list are fetched up front by the sub-group's lanes)
         const bool lane_meta = G > p.K;
@@ -718,9 +723,9 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     }
     {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
         bool handled = false;
-        int rc = agg_narrow_fwd(d, (hipStream_t)stream, &handled);
+        int rc = d->n_dyn ? KPGNN_OK : agg_narrow_fwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
-        rc = agg_small_fwd(d, (hipStream_t)stream, &handled);      // small batches: all hops of a node at once
+        if (!d->n_dyn) rc = agg_small_fwd(d, (hipStream_t)stream, &handled);      // small batches: all hops of a node at once
         if (rc != KPGNN_OK || handled) return rc;
     }
     FwdParams p;
@@ -733,7 +738,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         const size_t pt_b = (!d->periph && d->ptab && d->n_dict > 0) ? sizeof(float) * (size_t)d->n_dict * d->D : 0;
         if (pt_b && lds + pt_b <= cap) { p.lds_ptab = d->n_dict * d->D; lds += (pt_b + 15) & ~(size_t)15; }
     }
-    p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
     p.mode = d->mode; p.combine = combine ? 1 : 0; p.bf = d->storage == KPGNN_STORE_BF16 ? 1 : 0;
     KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "aggregate_fwd: unknown storage %d", d->storage);
     p.rowptr = d->rowptr; p.col = d->col; p.code = d->code; p.dis = d->dis;
@@ -794,11 +799,11 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
     }
     {   // narrow rows: the element-per-thread gather (aggregate_narrow.hip)
         bool handled = false;
-        const int rc = agg_narrow_bwd(d, (hipStream_t)stream, &handled);
+        const int rc = d->n_dyn ? KPGNN_OK : agg_narrow_bwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
     }
     BwdParams p;
-    p.N = d->N; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.K_csr = d->K_csr; p.n_code0 = d->n_code0; p.n_codek = d->K > 1 ? d->n_codek : 0;
     p.mode = d->mode; p.bf = d->storage == KPGNN_STORE_BF16 ? 1 : 0;
     KPGNN_REQUIRE(d->storage == KPGNN_STORE_F32 || d->storage == KPGNN_STORE_BF16, "aggregate_bwd: unknown storage %d", d->storage);
     p.rowptr = d->rowptr_src; p.col = d->col_src; p.code = d->code_src; p.dis = d->dis;
@@ -820,7 +825,7 @@ extern "C" int kpgnn_aggregate_bwd(const kpgnn_agg_bwd_desc* d, kpgnn_stream_t s
                 return fail(KPGNN_EINVAL, "aggregate_bwd: hop slots %d and %d share one gradient buffer with accumulate_mask set", a, b);
     {   // small batches: one block per node, all hops at once (aggregate_small.hip)
         bool handled = false;
-        const int rc = agg_small_bwd(d, (hipStream_t)stream, &handled);
+        const int rc = d->n_dyn ? KPGNN_OK : agg_small_bwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
     }
     if ((uint64_t)d->N * (uint64_t)d->g_sn * 4u >= (1ull << 32))

@@ -32,6 +32,7 @@ template <int VEC> __device__ __forceinline__ void stv(float* p, const float (&v
 }
 
 struct BnParams {
+    const int32_t* n_dyn;
     int64_t N; int C, relu; float eps, momentum;
     const float* x; int64_t xs;
     const float* dz; int64_t dzs;
@@ -98,7 +99,8 @@ __device__ __forceinline__ void block_to_slot_n(double* slot, int C, const doubl
 
 // fwd stats: sum x, sum x^2 (fp64: no pivot needed)
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_stats_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_stats_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
     double a[VEC], b[VEC];
@@ -132,7 +134,8 @@ __global__ void __launch_bounds__(kBlock) bn_stats_kernel(const BnParams p) {
 // fwd apply: every block finishes mean / invstd of the columns from the slot; block 0 publishes them and updates the
 // running statistics.  OUT: the statistics of z go to out_slot (z is then the input of another BatchNorm).
 template <int VEC, int G, bool OUT>
-__global__ void __launch_bounds__(kBlock) bn_apply_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_apply_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     __shared__ float cm[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
@@ -182,7 +185,8 @@ __global__ void __launch_bounds__(kBlock) bn_apply_kernel(const BnParams p) {
 
 // bwd reduce: s0 = sum dy, s1 = sum dy * xhat  (dy = dz masked by the recomputed pre-activation when relu)
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
     double a[VEC], b[VEC];
@@ -222,7 +226,8 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce_kernel(const BnParams p)
 // Stacked forward, pass 1: the statistics (sum z, sum z^2) of z = [relu](bn(x)) into out_slot WITHOUT writing z; every block
 // finishes bn's mean / invstd from in_slot, block 0 publishes them and updates the running statistics.
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_act_stats_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_act_stats_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     __shared__ float cm[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
@@ -280,7 +285,8 @@ __global__ void __launch_bounds__(kBlock) bn_act_stats_kernel(const BnParams p) 
 // Stacked forward, pass 2: out = bn_o([relu](bn(x))) + residual; bn's mean / invstd are read from where pass 1 published
 // them, bn_o's are finished from in_slot (the statistics of the intermediate) by every block.
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_apply2_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_apply2_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     __shared__ float cm[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     for (int c = threadIdx.x; c < p.C; c += kBlock) {
@@ -331,7 +337,8 @@ __global__ void __launch_bounds__(kBlock) bn_apply2_kernel(const BnParams p) {
 // (xi = xhat of the inner norm, m = [its pre-activation > 0], xo = xhat of the outer norm of z, z recomputed from y).
 // dz is never written: 3 launches (reduce, apply, reduce) and 100 MB per layer become 1 launch and 40 MB.
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_bwd_reduce2_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_bwd_reduce2_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     const bool col_ok = c0 < p.C;
     double t[8][VEC];
@@ -391,7 +398,8 @@ __global__ void __launch_bounds__(kBlock) bn_bwd_reduce2_kernel(const BnParams p
 }
 
 template <int VEC, int G>
-__global__ void __launch_bounds__(kBlock) bn_bwd_apply_kernel(const BnParams p) {
+__global__ void __launch_bounds__(kBlock) bn_bwd_apply_kernel(BnParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     __shared__ float cs[2][G * VEC];
     const int rl = threadIdx.x / G, sl = threadIdx.x % G, c0 = sl * VEC;
     for (int c = threadIdx.x; c < p.C; c += kBlock) {
@@ -472,7 +480,7 @@ extern "C" int kpgnn_bn_fwd(const kpgnn_bn_desc* d, kpgnn_stream_t stream) {
     int rc = bn_shape(d->C, {d->x, d->z, d->gamma, d->beta, d->residual}, {d->x_stride, d->z_stride, d->residual ? d->r_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
     BnParams p = {};
-    p.N = d->N; p.C = d->C; p.relu = d->relu; p.eps = d->eps; p.momentum = d->momentum;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.C = d->C; p.relu = d->relu; p.eps = d->eps; p.momentum = d->momentum;
     p.x = d->x; p.xs = d->x_stride; p.gamma = d->gamma; p.beta = d->beta; p.rmean = d->running_mean; p.rvar = d->running_var;
     p.mean = d->mean; p.invstd = d->invstd; p.z = d->z; p.zs = d->z_stride; p.res = d->residual; p.rs = d->r_stride;
     p.nbt = d->num_batches_tracked;
@@ -540,7 +548,7 @@ extern "C" int kpgnn_bn_bwd(const kpgnn_bn_bwd_desc* d, kpgnn_stream_t stream) {
                       {d->x_stride, d->dz_stride, d->dx ? d->dx_stride : 0, d->residual_grad ? d->rg_stride : 0}, &vec, &g);
     if (rc != KPGNN_OK) return rc;
     BnParams p = {};
-    p.N = d->N; p.C = d->C; p.relu = d->relu;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.C = d->C; p.relu = d->relu;
     p.x = d->x; p.xs = d->x_stride; p.dz = d->dz; p.dzs = d->dz_stride; p.gamma = d->gamma; p.beta = d->beta;
     p.mean = const_cast<float*>(d->mean); p.invstd = const_cast<float*>(d->invstd);
     p.z = d->dx; p.zs = d->dx_stride; p.dgamma = d->dgamma; p.dbeta = d->dbeta;

@@ -145,10 +145,14 @@ collate_tiles_kernel(const kpgnn_dataset_view ds, int B, const int32_t* __restri
 // cnt[(k-1) * ntiles + tile] = entries of the tile with hop < k, k = 1..P   (one wave per tile)
 __global__ void __launch_bounds__(kWave)
 prefix_count_kernel(const int32_t* __restrict__ tptr, const uint32_t* __restrict__ tpack, int P, int64_t ntiles,
-                    int32_t* __restrict__ cnt) {
+                    int32_t* __restrict__ cnt, const int32_t* __restrict__ n_dyn, int NT) {
     __shared__ int hist[64];
     const int lane = threadIdx.x;
     const int64_t tl = blockIdx.x;
+    if (n_dyn && tl >= ((int64_t)*n_dyn + NT - 1) / NT) {       // a tile beyond the live nodes (capacity launch): no entries
+        if (lane < P) cnt[(int64_t)lane * ntiles + tl] = 0;
+        return;
+    }
     hist[lane] = 0;
     __syncthreads();
     const int b = tptr[tl], e = tptr[tl + 1];
@@ -188,9 +192,10 @@ prefix_scan_kernel(const int32_t* __restrict__ cnt_all, int64_t n, int32_t* __re
 // wave (tile, k-1): stable compaction of the entries with hop < k
 __global__ void __launch_bounds__(kWave)
 prefix_compact_kernel(const int32_t* __restrict__ tptr, const uint32_t* __restrict__ tpack, int64_t ntiles, int64_t pack_stride,
-                      const int32_t* __restrict__ optr_all, uint32_t* __restrict__ opack_all) {
+                      const int32_t* __restrict__ optr_all, uint32_t* __restrict__ opack_all, const int32_t* __restrict__ n_dyn, int NT) {
     const int lane = threadIdx.x;
     const int64_t tl = blockIdx.x;
+    if (n_dyn && tl >= ((int64_t)*n_dyn + NT - 1) / NT) return;
     const int k = blockIdx.y + 1;
     const int32_t* optr = optr_all + (int64_t)blockIdx.y * (ntiles + 1);
     uint32_t* opack = opack_all + (int64_t)blockIdx.y * pack_stride;
@@ -225,19 +230,20 @@ using namespace kpgnn;
 
 extern "C" int kpgnn_tile_pack_prefixes(const int32_t* tile_ptr, const uint32_t* tile_pack, int64_t num_tiles, int32_t num_prefix,
                                         int64_t pack_stride, int32_t* out_ptr, uint32_t* out_pack, int32_t* scratch,
-                                        kpgnn_stream_t stream) {
+                                        const int32_t* n_dyn, int32_t nodes_per_tile, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(!n_dyn || nodes_per_tile >= 1, "tile_pack_prefixes: n_dyn needs nodes_per_tile");
     KPGNN_REQUIRE(num_tiles >= 0 && num_tiles < (1ll << 30) && num_prefix >= 0 && num_prefix <= 62 && pack_stride >= 0,
                   "tile_pack_prefixes: bad num_tiles=%lld num_prefix=%d", (long long)num_tiles, num_prefix);
     if (num_tiles == 0 || num_prefix == 0) return KPGNN_OK;
     KPGNN_REQUIRE(tile_ptr && tile_pack && out_ptr && out_pack && scratch, "tile_pack_prefixes: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(prefix_count_kernel, dim3((unsigned)num_tiles), dim3(kWave), 0, s, tile_ptr, tile_pack, (int)num_prefix,
-                       num_tiles, scratch);
+                       num_tiles, scratch, n_dyn, (int)nodes_per_tile);
     KPGNN_LAUNCH_CHECK("prefix_count_kernel");
     hipLaunchKernelGGL(prefix_scan_kernel, dim3((unsigned)num_prefix), dim3(1024), 0, s, scratch, num_tiles, out_ptr);
     KPGNN_LAUNCH_CHECK("prefix_scan_kernel");
     hipLaunchKernelGGL(prefix_compact_kernel, dim3((unsigned)num_tiles, (unsigned)num_prefix), dim3(kWave), 0, s, tile_ptr,
-                       tile_pack, num_tiles, pack_stride, out_ptr, out_pack);
+                       tile_pack, num_tiles, pack_stride, out_ptr, out_pack, n_dyn, (int)nodes_per_tile);
     KPGNN_LAUNCH_CHECK("prefix_compact_kernel");
     return KPGNN_OK;
 }
@@ -283,7 +289,7 @@ extern "C" int kpgnn_collate(const kpgnn_collate_desc* d, kpgnn_stream_t stream)
         KPGNN_LAUNCH_CHECK("collate_tiles_kernel");
         if (d->num_prefix > 0 && ntiles > 0)
             return kpgnn_tile_pack_prefixes(d->tile_ptr, d->tile_pack, ntiles, d->num_prefix, d->n_ent, d->prefix_ptr, d->prefix_pack,
-                                            d->prefix_scratch, stream);
+                                            d->prefix_scratch, d->hdr + 2 * d->B, d->nodes_per_tile, stream);
     }
     return KPGNN_OK;
 }

@@ -31,6 +31,7 @@ constexpr int kThreadsDG = kWave * kWavesDG;
 constexpr int kChunk = 64;                  // nodes per staged chunk of gh
 
 struct DgParams {
+    const int32_t* n_dyn;
     int N, K, D, U;
     const int32_t* uid; int64_t uid_stride;
     const float* theta;
@@ -41,7 +42,8 @@ struct DgParams {
 
 // LDS (floats): acc [U*K][D] | ghs [2][kChunk][D]
 __global__ void __launch_bounds__(kThreadsDG)
-dict_grad_kernel(const DgParams p) {
+dict_grad_kernel(DgParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
@@ -255,7 +257,7 @@ extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t str
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "dict_grad: workspace too small (%zu < %zu)",
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     DgParams p;
-    p.N = d->N; p.K = d->K; p.D = d->D; p.U = d->n_dict;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.U = d->n_dict;
     p.uid = d->uid; p.uid_stride = d->uid_stride; p.theta = d->theta; p.gh = d->gh; p.slab = (float*)d->workspace;
     p.dom = d->dominant;
     if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)dict_grad_kernel, pl.lds));

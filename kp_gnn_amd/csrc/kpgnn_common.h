@@ -41,6 +41,15 @@ inline int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int kWave = 64;   // CDNA wavefront
+
+// Live row count of a launch whose descriptor carries a CAPACITY N and an optional device-side count (kpgnn.h, `n_dyn`): a
+// hipGraph captured once for the capacity then serves batches of any size up to it.  One scalar load at kernel entry.
+template <typename T>
+__device__ __forceinline__ T live_rows(T N, const int32_t* n_dyn) {
+    if (!n_dyn) return N;
+    const T n = (T)*n_dyn;
+    return n < N ? (n < 0 ? (T)0 : n) : N;
+}
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
 
 struct DeviceFacts {

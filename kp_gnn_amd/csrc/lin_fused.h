@@ -41,6 +41,7 @@ namespace kpgnn {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct LinFParams {
+    const int32_t* n_dyn;
     int64_t N; int O, I, pitch, wt;
     const float* x; const float* w; const float* bias; float* y;
     // PRO 1 / 2
@@ -70,7 +71,9 @@ __device__ __forceinline__ double slot_sum(const double* slot, int C, int which,
 
 template <int KS, int M, int PRO, int EPI>
 __global__ void __launch_bounds__(256, 2)
-lin_fused_kernel(const LinFParams p) {
+lin_fused_kernel(LinFParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
+    if (p.N <= 0) return;                             // (only under a dynamic count of zero)
     extern __shared__ __attribute__((aligned(16))) float xl[];      // [32*M][pitch] tile, then the coefficient rows
     constexpr int ROWS = 32 * M;
     constexpr int I = 2 * KS, CGI = I / 4, RLI = 256 / CGI, NAI = CGI * RLI, PFI = (ROWS + RLI - 1) / RLI;

@@ -15,7 +15,7 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
     if (!d->w_transposed) al |= (uintptr_t)d->w;
     if (al & 15) return fail(KPGNN_ELIMIT, "linear_bn: operands must be 16-B aligned");
     LinFParams p = {};
-    p.N = d->N; p.O = d->O; p.I = d->I; p.wt = d->w_transposed ? 1 : 0;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.O = d->O; p.I = d->I; p.wt = d->w_transposed ? 1 : 0;
     p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y;
     if (d->pro != 0) {
         KPGNN_REQUIRE(d->in_slot && d->in_gamma && d->in_beta && d->in_mean && d->in_invstd, "linear_bn: pro %d needs in_slot, in_gamma, in_beta, in_mean, in_invstd", d->pro);

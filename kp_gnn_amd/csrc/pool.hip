@@ -28,6 +28,7 @@ template <int VEC> __device__ __forceinline__ void stv(float* p, const float (&v
 }
 
 struct PoolParams {
+    const int32_t* n_dyn;
     int64_t N; int G, D, mean;
     const int32_t* ptr; const int64_t* batch;
     const float* x; int64_t xs;
@@ -36,7 +37,8 @@ struct PoolParams {
 };
 
 template <int VEC, int L>
-__global__ void __launch_bounds__(kBlock) pool_fwd_kernel(const PoolParams p) {
+__global__ void __launch_bounds__(kBlock) pool_fwd_kernel(PoolParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     const int sg = threadIdx.x / L, sl = threadIdx.x % L, c0 = sl * VEC;
     const int64_t g = (int64_t)blockIdx.x * (kBlock / L) + sg;
     if (g >= p.G || c0 >= p.D) return;
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(kBlock) pool_fwd_kernel(const PoolParams p) {
 }
 
 template <int VEC, int L>
-__global__ void __launch_bounds__(kBlock) pool_bwd_kernel(const PoolParams p) {
+__global__ void __launch_bounds__(kBlock) pool_bwd_kernel(PoolParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     const int sg = threadIdx.x / L, sl = threadIdx.x % L, c0 = sl * VEC;
     if (c0 >= p.D) return;
     for (int64_t n = (int64_t)blockIdx.x * (kBlock / L) + sg; n < p.N; n += (int64_t)gridDim.x * (kBlock / L)) {
@@ -135,7 +138,7 @@ extern "C" int kpgnn_segment_pool_fwd(const kpgnn_pool_desc* d, kpgnn_stream_t s
     rc = shape(d->D, {d->x, d->out}, {d->x_stride}, &vec, &lanes);
     if (rc != KPGNN_OK) return rc;
     PoolParams p = {};
-    p.N = d->N; p.G = d->G; p.D = d->D; p.mean = d->mode; p.ptr = d->graph_ptr; p.x = d->x; p.xs = d->x_stride; p.out = d->out;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.G = d->G; p.D = d->D; p.mean = d->mode; p.ptr = d->graph_ptr; p.x = d->x; p.xs = d->x_stride; p.out = d->out;
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)((d->G + (kBlock / lanes) - 1) / (kBlock / lanes));
     KP_POOL_SWITCH(pool_fwd_kernel, grid);
@@ -151,7 +154,7 @@ extern "C" int kpgnn_segment_pool_bwd(const kpgnn_pool_desc* d, kpgnn_stream_t s
     rc = shape(d->D, {d->gout, d->gx}, {d->gx_stride}, &vec, &lanes);
     if (rc != KPGNN_OK) return rc;
     PoolParams p = {};
-    p.N = d->N; p.G = d->G; p.D = d->D; p.mean = d->mode; p.ptr = d->graph_ptr; p.batch = d->batch;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.G = d->G; p.D = d->D; p.mean = d->mode; p.ptr = d->graph_ptr; p.batch = d->batch;
     p.gout = d->gout; p.gx = d->gx; p.gxs = d->gx_stride;
     hipStream_t s = (hipStream_t)stream;
     const int rows = kBlock / lanes;

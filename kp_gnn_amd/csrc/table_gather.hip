@@ -24,6 +24,7 @@ template <> struct VT<2> { using T = float2; };
 template <> struct VT<4> { using T = float4; };
 
 struct TgsParams {
+    const int32_t* n_dyn;
     int64_t M;
     int C, D, R, Ds;            // Ds = columns per split
     const uint16_t* idx;
@@ -37,7 +38,8 @@ struct TgsParams {
 
 template <int VEC, int G>
 __global__ void __launch_bounds__(kBlock)
-tgs_kernel(const TgsParams p) {
+tgs_kernel(TgsParams p) {
+    p.M = live_rows(p.M, p.n_dyn);
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [R, Ds]
     const int Ds = p.Ds, R = p.R;
     const int col_base = blockIdx.y * Ds;
@@ -101,7 +103,8 @@ constexpr int kSmallPairs = 4096;
 constexpr int kSmallBlock = 128;
 
 __global__ void __launch_bounds__(kSmallBlock)
-tgs_small_fwd_kernel(const TgsParams p) {
+tgs_small_fwd_kernel(TgsParams p) {
+    p.M = live_rows(p.M, p.n_dyn);
     const int64_t m = blockIdx.x;
     const uint16_t* ix = p.idx + m * p.C;
     for (int col = threadIdx.x; col < p.D; col += kSmallBlock) {
@@ -120,7 +123,8 @@ tgs_small_fwd_kernel(const TgsParams p) {
 }
 
 __global__ void __launch_bounds__(kSmallBlock)
-tgs_small_bwd_kernel(const TgsParams p) {
+tgs_small_bwd_kernel(TgsParams p) {
+    p.M = live_rows(p.M, p.n_dyn);
     const int r = blockIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     const int pairs = (int)p.M * p.C;
@@ -152,7 +156,7 @@ bool tgs_small(const kpgnn_tgs_desc* d) {
 
 TgsParams tgs_params(const kpgnn_tgs_desc* d) {
     TgsParams p;
-    p.M = d->M; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = d->D; p.idx = d->idx; p.col_offset = d->col_offset;
+    p.M = d->M; p.n_dyn = d->n_dyn; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = d->D; p.idx = d->idx; p.col_offset = d->col_offset;
     p.table = d->table; p.bias = d->bias; p.out = d->out; p.out_stride = d->out_stride;
     p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
     return p;
@@ -166,7 +170,8 @@ TgsParams tgs_params(const kpgnn_tgs_desc* d) {
 // (ds_add_f32) all the same: a plain `+=` is a load-add-store chain that waits for the LDS latency at every index, while
 // the fire-and-forget form keeps the LDS pipeline full and stays ordered per address within a wave.
 __global__ void __launch_bounds__(kBlock)
-tgs_bwd_kernel(const TgsParams p, int CW, int NG, float* __restrict__ slab, int csplit) {
+tgs_bwd_kernel(TgsParams p, int CW, int NG, float* __restrict__ slab, int csplit) {
+    p.M = live_rows(p.M, p.n_dyn);
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [NG][R][CW]
     const int Ds = p.Ds, R = p.R;
     const int col_base = blockIdx.y * Ds;
@@ -381,7 +386,7 @@ int run_bwd(const kpgnn_tgs_desc* d, hipStream_t s) {
     KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_gather_sum_bwd: workspace too small (%zu < %zu)",
                   (size_t)d->workspace_bytes, pl.ws_bytes);
     TgsParams p;
-    p.M = d->M; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = pl.Ds; p.idx = d->idx; p.col_offset = d->col_offset;
+    p.M = d->M; p.n_dyn = d->n_dyn; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = pl.Ds; p.idx = d->idx; p.col_offset = d->col_offset;
     p.table = nullptr; p.bias = nullptr; p.out = nullptr; p.out_stride = 0;
     p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
     KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tgs_bwd_kernel, pl.lds));
@@ -423,7 +428,7 @@ int run(const kpgnn_tgs_desc* d, hipStream_t s) {
     }
     if (!splits) return fail(KPGNN_ELIMIT, "table_gather_sum: R=%d rows do not fit LDS at any column split of D=%d", d->R, d->D);
     TgsParams p;
-    p.M = d->M; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = Ds; p.idx = d->idx; p.col_offset = d->col_offset;
+    p.M = d->M; p.n_dyn = d->n_dyn; p.C = d->C; p.D = d->D; p.R = d->R; p.Ds = Ds; p.idx = d->idx; p.col_offset = d->col_offset;
     p.table = d->table; p.bias = d->bias; p.out = d->out; p.out_stride = d->out_stride;
     p.gout = d->gout; p.gout_stride = d->gout_stride; p.gtable = d->gtable;
     const size_t lds = (size_t)d->R * Ds * sizeof(float);

@@ -29,6 +29,7 @@ constexpr int kMaxRows = 64;                // NT*K: at most 8 nodes x 8 hops pe
 constexpr int kSlotRows = 2 * kWavesTG;     // first-run slots: [list][wave]
 
 struct TgParams {
+    const int32_t* n_dyn;
     int N, K, D, NT, n0, nk, U, dict_src, KD;
     const int32_t* tptr;
     const uint32_t* tpack;
@@ -85,7 +86,8 @@ template <> struct Cols<2> {
 // stride the k = 8 launch took 132 instead of 126 us).
 template <int CPL, bool VEC4, bool BF = false, bool FUSE = false, bool WPH1 = false>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // (HIP: waves per SIMD) two blocks per CU: 128 VGPRs
-table_grad_kernel(const TgParams p, int AS) {
+table_grad_kernel(TgParams p, int AS) {
+    p.N = live_rows(p.N, p.n_dyn);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using CV = Cols<CPL>;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform: keeps the walk in SALU control flow
@@ -781,7 +783,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
                       "table_grad(fused combine): theta-gradient workspace too small");
         KPGNN_REQUIRE(!d->fuse_galphas || (d->fuse_alphas && d->fuse_gtheta), "table_grad(fused combine): galphas needs alphas and gtheta");
         TgParams p;
-        p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
+        p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
         p.n0 = d->n_code0; p.nk = d->K > 1 ? d->n_codek : 0; p.U = d->n_dict; p.dict_src = d->n_dict > 0 ? 1 : 0; p.KD = d->dict_pack_K;
         p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = nullptr;
         p.uid = d->uid; p.uid_stride = d->uid_stride; p.dpack = d->n_dict > 0 ? d->dict_pack : nullptr; p.theta = d->theta; p.gh = d->gh;
@@ -831,7 +833,7 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         }
     }
     TgParams p;
-    p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile;
     p.n0 = edges ? d->n_code0 : 0; p.nk = (edges && d->K > 1) ? d->n_codek : 0;
     p.U = d->n_dict; p.dict_src = d->dict_src;
     p.tptr = d->tile_ptr; p.tpack = d->tile_pack; p.g = d->g;

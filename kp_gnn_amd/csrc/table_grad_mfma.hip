@@ -27,6 +27,7 @@ constexpr int kTgmPF = 8;     // float4 registers per thread of the prefetched g
 __device__ __forceinline__ int mult_of(uint32_t w) { return (int)((w >> 6) & 0x3Fu) + 1; }   // merged-entry multiplicity
 
 struct TgmParams {
+    const int32_t* n_dyn;
     int N, K, D, NT, n0, U, dict_src;
     int RE, REp, Rp, R, MT, MTE, rows, QS, CP, NTILES, KQ, vec4;
     const int32_t* tptr;
@@ -40,7 +41,8 @@ struct TgmParams {
 
 template <int MAXIT, int MTMAX>
 __global__ void __launch_bounds__(kTgmThreads)
-table_grad_mfma_kernel(const TgmParams p) {
+table_grad_mfma_kernel(TgmParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = p.D, K = p.K, rows = p.rows, CP = p.CP, QS = p.QS;
     const int tile_floats = rows * D;
@@ -293,7 +295,7 @@ int table_grad_mfma(const kpgnn_table_grad_desc* d, hipStream_t s, bool* handled
     if (!tgm_plan(d->N, d->K, d->D, d->nodes_per_tile, n0, nk, d->n_dict, dsrc1, &pl)) return KPGNN_OK;
     if (!d->workspace || d->workspace_bytes < pl.ws_bytes) return KPGNN_OK;
     TgmParams p;
-    p.N = d->N; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile; p.n0 = n0; p.U = d->n_dict; p.dict_src = d->dict_src;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = d->K; p.D = d->D; p.NT = d->nodes_per_tile; p.n0 = n0; p.U = d->n_dict; p.dict_src = d->dict_src;
     p.RE = pl.RE; p.REp = pl.REp; p.Rp = pl.Rp; p.R = pl.R; p.MT = pl.MT; p.MTE = pl.MTE; p.rows = pl.rows; p.QS = pl.QS;
     p.CP = pl.CP; p.NTILES = pl.NTILES; p.KQ = pl.KQ;
     p.vec4 = (((int64_t)d->K * d->D) % 4 == 0) && ((((uintptr_t)d->g) & 15) == 0);

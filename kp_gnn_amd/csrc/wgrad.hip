@@ -646,11 +646,11 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
         (((uintptr_t)d->x | (uintptr_t)d->y) & 15) != 0 || (d->bias && (((uintptr_t)d->bias) & 15) != 0))
         return fail(KPGNN_ELIMIT, "linear_fwd: needs contiguous 16-B aligned x / y with I %% 4 == 0 and O %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
-    if (d->O <= 128 && (d->x_mask || d->n_dyn)) return fail(KPGNN_ELIMIT, "linear_fwd: x_mask / n_dyn are implemented for O > 128");
+    if (d->O <= 128 && d->x_mask) return fail(KPGNN_ELIMIT, "linear_fwd: x_mask is implemented for O > 128");
     if (d->x_mask && (((uintptr_t)d->x_mask) & 15) != 0) return fail(KPGNN_ELIMIT, "linear_fwd: x_mask must be 16-B aligned");
     if (d->O <= 128) {                                  // the plain variant of the fused kernel (lin_fused.h)
         kpgnn_linear_bn_desc f = {};
-        f.N = d->N; f.O = d->O; f.I = d->I; f.x = d->x; f.w = d->w; f.bias = d->bias; f.y = d->y; f.w_transposed = d->w_transposed;
+        f.N = d->N; f.n_dyn = d->n_dyn; f.O = d->O; f.I = d->I; f.x = d->x; f.w = d->w; f.bias = d->bias; f.y = d->y; f.w_transposed = d->w_transposed;
         return kpgnn_linear_bn(&f, stream);
     }
     if (d->I != 32 && d->I != 64 && d->I != 104 && d->I != 128)

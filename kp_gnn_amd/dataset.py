@@ -269,77 +269,68 @@ class KHopDataset:
             v.ent_rel, v.ent = self.ent_rel.data_ptr(), self.ent.data_ptr()
         return v
 
-    def collate(self, ids, prefixes=True):
-        """Batch of the graphs `ids` (dataset indices, in batch order) as a KHopBatch whose CSR, entry lists, dictionary ids
-        and readout offsets are already in place: no layer call, encoder or readout pays a build or a host sync for it.
-        `edge_index` / `edge_attr` of the result are zero-length HANDLES ([2,0] / [0,K]): the layers only use them to find
-        the attached CSR (and to slice the hop prefix `edge_attr[:, :k]`), the [E]-sized int64 tensors are never made."""
-        lib = _lib.load()
+    def _buffers(self, B, N, A, n_ent, hdr, prefixes=True):
+        """Output buffers of one collate call for B graphs / N nodes / A pairs / n_ent entries (exact sizes, or the capacities
+        of a StaticBatch), wired into a KHopBatch with its CSR, entry lists, dictionary ids and readout offsets in place, and
+        the kpgnn_collate descriptor that fills them.  `hdr`: the device int32[4B+3] header the call will read."""
         dev = self.device
-        hdr_h, B, N, A, n_ent = self.plan(ids)
         K = self.K
-        with torch.cuda.device(dev):
-            hdr = torch.from_numpy(hdr_h).pin_memory().to(dev, non_blocking=True)
-            i32 = dict(dtype=torch.int32, device=dev)
-            c = KHopCSR()
-            c.N, c.K, c.A, c.device = N, K, A, dev
-            c.E = int(self.h_edges[hdr_h[:B]].sum())
-            c.max_code0, c.max_codek = self.max_code0, self.max_codek
-            c.rowptr_dst, c.rowptr_src = torch.empty(N * K + 1, **i32), torch.empty(N * K + 1, **i32)
-            c.col_dst, c.col_src = torch.empty(max(A, 1), **i32), torch.empty(max(A, 1), **i32)
-            c.code_dst = torch.empty(max(A, 1), dtype=torch.int16, device=dev)
-            c.code_src = torch.empty(max(A, 1), dtype=torch.int16, device=dev)
-            c.nodes_per_tile = NT = self.NODES_PER_TILE
-            hp = self.h_hop_pairs[hdr_h[:B]].sum(0)
-            c._apairs = {k + 1: int(hp[k]) for k in range(K - 1)}
-            batch_vec = torch.empty(N, dtype=torch.int64, device=dev)
-            node_src = torch.empty(N, **i32)
-            d = _lib.CollateDesc()
-            d.ds = self._view()
-            d.B, d.N, d.A, d.n_ent, d.hdr = B, N, A, n_ent, hdr.data_ptr()
-            d.rowptr_dst, d.col_dst, d.code_dst = c.rowptr_dst.data_ptr(), c.col_dst.data_ptr(), c.code_dst.data_ptr()
-            d.rowptr_src, d.col_src, d.code_src = c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr()
-            d.batch, d.node_src = batch_vec.data_ptr(), node_src.data_ptr()
-            keep = [hdr, node_src]
-            if self.has_entries:
-                ntiles = (N + NT - 1) // NT
-                c.tile_ptr, c.tile_pack = torch.empty(ntiles + 1, **i32), torch.empty(max(n_ent, 1), **i32)
-                enp = torch.empty(N + 1, **i32)
-                d.nodes_per_tile, d.tile_ptr, d.tile_pack, d.ent_node_ptr = NT, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(), enp.data_ptr()
-                keep.append(enp)
-                P = K - 1 if (prefixes and ntiles > 0) else 0
-                if P > 0:
-                    pptr = torch.empty((P, ntiles + 1), **i32)
-                    ppack = torch.empty((P, max(n_ent, 1)), **i32)
-                    pscr = torch.empty((P, ntiles), **i32)
-                    d.num_prefix, d.prefix_ptr, d.prefix_pack, d.prefix_scratch = P, pptr.data_ptr(), ppack.data_ptr(), pscr.data_ptr()
-                    keep.append(pscr)
-                    c._tile_lists = {k: (pptr[k - 1], ppack[k - 1]) for k in range(1, K)}
-            else:
-                c.tile_ptr = c.tile_pack = None
-            out = KHopBatch(num_graphs=B)
-            rows = []
-            for name, src in self.node_rows.items():
-                dst = torch.empty((N,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
-                rows.append((src, dst))
-                setattr(out, name, dst)
-            uid = None
-            if self.uid is not None:
-                uid = torch.empty((N, K), **i32)
-                rows.append((self.uid, uid))
-            if len(rows) > 8 or len(self.graph_rows) > 8:
-                raise _lib.KpgnnError("at most 8 node-level and 8 graph-level attributes per collate")
-            d.n_node_rows = len(rows)
-            for j, (src, dst) in enumerate(rows):
-                d.node_rows[j].src, d.node_rows[j].dst = src.data_ptr(), dst.data_ptr()
-                d.node_rows[j].row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
-            d.n_graph_rows = len(self.graph_rows)
-            for j, (name, src) in enumerate(self.graph_rows.items()):
-                dst = torch.empty((B,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
-                d.graph_rows[j].src, d.graph_rows[j].dst = src.data_ptr(), dst.data_ptr()
-                d.graph_rows[j].row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
-                setattr(out, name, dst)
-            _lib.check(lib.kpgnn_collate(ctypes.byref(d), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_collate")
+        i32 = dict(dtype=torch.int32, device=dev)
+        c = KHopCSR()
+        c.N, c.K, c.A, c.device = N, K, A, dev
+        c.max_code0, c.max_codek = self.max_code0, self.max_codek
+        c.rowptr_dst, c.rowptr_src = torch.empty(N * K + 1, **i32), torch.empty(N * K + 1, **i32)
+        c.col_dst, c.col_src = torch.empty(max(A, 1), **i32), torch.empty(max(A, 1), **i32)
+        c.code_dst = torch.empty(max(A, 1), dtype=torch.int16, device=dev)
+        c.code_src = torch.empty(max(A, 1), dtype=torch.int16, device=dev)
+        c.nodes_per_tile = NT = self.NODES_PER_TILE
+        batch_vec = torch.empty(N, dtype=torch.int64, device=dev)
+        node_src = torch.empty(N, **i32)
+        d = _lib.CollateDesc()
+        d.ds = self._view()
+        d.B, d.N, d.A, d.n_ent, d.hdr = B, N, A, n_ent, hdr.data_ptr()
+        d.rowptr_dst, d.col_dst, d.code_dst = c.rowptr_dst.data_ptr(), c.col_dst.data_ptr(), c.code_dst.data_ptr()
+        d.rowptr_src, d.col_src, d.code_src = c.rowptr_src.data_ptr(), c.col_src.data_ptr(), c.code_src.data_ptr()
+        d.batch, d.node_src = batch_vec.data_ptr(), node_src.data_ptr()
+        keep = [hdr, node_src]
+        if self.has_entries:
+            ntiles = (N + NT - 1) // NT
+            c.tile_ptr, c.tile_pack = torch.empty(ntiles + 1, **i32), torch.empty(max(n_ent, 1), **i32)
+            enp = torch.empty(N + 1, **i32)
+            d.nodes_per_tile, d.tile_ptr, d.tile_pack, d.ent_node_ptr = NT, c.tile_ptr.data_ptr(), c.tile_pack.data_ptr(), enp.data_ptr()
+            keep.append(enp)
+            P = K - 1 if (prefixes and ntiles > 0) else 0
+            if P > 0:
+                pptr = torch.empty((P, ntiles + 1), **i32)
+                ppack = torch.empty((P, max(n_ent, 1)), **i32)
+                pscr = torch.empty((P, ntiles), **i32)
+                d.num_prefix, d.prefix_ptr, d.prefix_pack, d.prefix_scratch = P, pptr.data_ptr(), ppack.data_ptr(), pscr.data_ptr()
+                keep.append(pscr)
+                c._tile_lists = {k: (pptr[k - 1], ppack[k - 1]) for k in range(1, K)}
+        else:
+            c.tile_ptr = c.tile_pack = None
+        out = KHopBatch(num_graphs=B)
+        rows = []
+        for name, src in self.node_rows.items():
+            dst = torch.empty((N,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+            rows.append((src, dst))
+            setattr(out, name, dst)
+        uid = None
+        if self.uid is not None:
+            uid = torch.empty((N, K), **i32)
+            rows.append((self.uid, uid))
+        if len(rows) > 8 or len(self.graph_rows) > 8:
+            raise _lib.KpgnnError("at most 8 node-level and 8 graph-level attributes per collate")
+        d.n_node_rows = len(rows)
+        for j, (src, dst) in enumerate(rows):
+            d.node_rows[j].src, d.node_rows[j].dst = src.data_ptr(), dst.data_ptr()
+            d.node_rows[j].row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
+        d.n_graph_rows = len(self.graph_rows)
+        for j, (name, src) in enumerate(self.graph_rows.items()):
+            dst = torch.empty((B,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+            d.graph_rows[j].src, d.graph_rows[j].dst = src.data_ptr(), dst.data_ptr()
+            d.graph_rows[j].row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
+            setattr(out, name, dst)
         c._keep = keep
         # integer node attributes arrive validated (dataset-wide maximum): the encoders skip their range check
         for name, hi in self.index_bounds.items():
@@ -351,7 +342,6 @@ class KHopDataset:
         setattr(batch_vec, _GPTR, ((batch_vec._version, B), hdr[B:2 * B + 1]))
         out.edge_index = torch.empty((2, 0), dtype=torch.int64, device=dev)
         out.edge_attr = torch.empty((0, K), dtype=torch.int64, device=dev)
-        out.num_khop_edges = c.E
         out.csr = c
         attach_khop_csr(out.edge_index, out.edge_attr, N, c)
         if K > 1:
@@ -359,7 +349,92 @@ class KHopDataset:
         if uid is not None:
             uid._kp_dom = self.pdict.dominant
             out.peripheral_dict = BatchPeripheral(self.pdict, uid)
+        return out, c, d
+
+    def collate(self, ids, prefixes=True):
+        """Batch of the graphs `ids` (dataset indices, in batch order) as a KHopBatch whose CSR, entry lists, dictionary ids
+        and readout offsets are already in place: no layer call, encoder or readout pays a build or a host sync for it.
+        `edge_index` / `edge_attr` of the result are zero-length HANDLES ([2,0] / [0,K]): the layers only use them to find
+        the attached CSR (and to slice the hop prefix `edge_attr[:, :k]`), the [E]-sized int64 tensors are never made."""
+        lib = _lib.load()
+        dev = self.device
+        hdr_h, B, N, A, n_ent = self.plan(ids)
+        with torch.cuda.device(dev):
+            hdr = torch.from_numpy(hdr_h).pin_memory().to(dev, non_blocking=True)
+            out, c, d = self._buffers(B, N, A, n_ent, hdr, prefixes)
+            c.E = int(self.h_edges[hdr_h[:B]].sum())
+            hp = self.h_hop_pairs[hdr_h[:B]].sum(0)
+            c._apairs = {k + 1: int(hp[k]) for k in range(self.K - 1)}
+            _lib.check(lib.kpgnn_collate(ctypes.byref(d), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_collate")
+        out.num_khop_edges = c.E
         return out
+
+    def capacities(self, B, sigmas=6.0):
+        """(N, A, entries) that a batch of B graphs drawn without replacement stays below with overwhelming probability:
+        B * mean + sigmas * std * sqrt(B) of the per-graph counts (+ one graph's maximum), never more than the B largest."""
+        caps = []
+        for cnt in (self.h_nodes, self.h_pairs, self.h_ents):
+            c = np.asarray(cnt, dtype=np.float64)
+            top = float(np.sort(c)[-min(B, c.size):].sum())
+            est = B * c.mean() + sigmas * c.std() * np.sqrt(B) + c.max()
+            caps.append(int(min(top, np.ceil(est))) if B < c.size else int(top))
+        return tuple(caps)
+
+    def static_batch(self, B, capacities=None):
+        return StaticBatch(self, B, capacities or self.capacities(B))
+
+
+class CapacityError(_lib.KpgnnError):
+    pass
+
+
+class StaticBatch:
+    """A batch whose tensors have FIXED addresses and CAPACITY shapes, refilled in place by every collate: what a captured
+    hipGraph of the training step needs.  Every tensor of `self.batch` is allocated for `N_cap` nodes; the number of LIVE
+    nodes of the current batch sits in the device-side header (`self.live_nodes`, int32[1]) and reaches the kernels as
+    their descriptors' n_dyn (ops.dynamic_rows), so that rows beyond it are never read, written or summed.
+
+        sb = dataset.static_batch(B)
+        with sb.dynamic():                        # every launch on N_cap rows gets the live count
+            sb.stage(ids); sb.launch_collate(); step(sb.batch)        # eager, or inside a hipGraph capture
+        ...
+        sb.stage(ids_next); graph.replay()        # per step: 16 KB of header to the device, one graph launch
+    """
+
+    def __init__(self, ds, B, capacities):
+        self.ds, self.B = ds, int(B)
+        self.N_cap, self.A_cap, self.E_cap = (int(v) for v in capacities)
+        dev = ds.device
+        with torch.cuda.device(dev):
+            self.hdr = torch.zeros(4 * self.B + 3, dtype=torch.int32, device=dev)
+            self.batch, self.csr, self._desc = ds._buffers(self.B, self.N_cap, self.A_cap, self.E_cap, self.hdr)
+        self.csr.E = self.A_cap
+        self.csr._apairs = {k: self.A_cap for k in range(1, ds.K)}          # (byte accounting only: upper bounds)
+        self.live_nodes = self.hdr[2 * self.B:2 * self.B + 1]
+        self.live = None            # (N, A, entries) of the staged batch
+
+    def dynamic(self):
+        from .ops import dynamic_rows
+        return dynamic_rows(self.live_nodes, self.N_cap)
+
+    def stage(self, ids):
+        """Host side of a collate: plan the batch and send its header (asynchronously, stream-ordered).  Raises CapacityError
+        when the batch does not fit the static buffers (the caller then takes an exact-shape `dataset.collate(ids)` step)."""
+        hdr_h, B, N, A, n_ent = self.ds.plan(ids)
+        if B != self.B:
+            raise ValueError(f"StaticBatch built for {self.B} graphs, got {B}")
+        if N > self.N_cap or A > self.A_cap or n_ent > self.E_cap:
+            raise CapacityError(f"batch of {N} nodes / {A} pairs / {n_ent} entries exceeds the static capacity "
+                                f"{self.N_cap} / {self.A_cap} / {self.E_cap}")
+        with torch.cuda.device(self.ds.device):
+            self.hdr.copy_(torch.from_numpy(hdr_h).pin_memory(), non_blocking=True)
+        self.live = (N, A, n_ent)
+
+    def launch_collate(self):
+        """Device side: kpgnn_collate into the static buffers (capturable: its arguments never change)."""
+        dev = self.ds.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().kpgnn_collate(ctypes.byref(self._desc), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_collate")
 
 
 def _zero_pe(dev, width, n):

@@ -67,7 +67,8 @@ class KHopCSR:
 
     def gcn_dis(self):
         """deg^-1/2 per (node,hop) with the KP-GCN self loop counted (layers/KPGCN.py:11-25,106-108)."""
-        if self._dis is None:
+        from .ops import dyn_ptr
+        if self._dis is None or dyn_ptr(self.N) is not None:     # (a StaticBatch refills rowptr in place: no caching there)
             deg = (self.rowptr_dst[1:] - self.rowptr_dst[:-1] + 1).to(torch.float32)
             self._dis = deg.pow(-0.5).contiguous()
         return self._dis

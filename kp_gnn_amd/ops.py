@@ -85,6 +85,44 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# ------------------------------------------------------------------------------------ dynamic row count (static-shape graphs)
+# A hipGraph bakes every kernel argument in, the row count N of a batch included, and no two shuffled batches have the same
+# N.  Under `dynamic_rows(count, capacity)` every launch that works on `capacity` rows is handed `count` (a device int32[1],
+# e.g. the node count kpgnn_collate leaves in its header) as its descriptor's n_dyn: tensors are allocated for the capacity,
+# kernels read, write and SUM only the live rows - so ONE captured graph serves every batch up to the capacity
+# (dataset.StaticBatch, bench.py --fresh-batches).  Operators without an n_dyn field refuse to run in this mode.
+_DYN = None     # (count tensor, capacity)
+
+
+class dynamic_rows:
+    def __init__(self, count, capacity):
+        assert count.dtype == torch.int32 and count.numel() >= 1 and count.is_cuda
+        self._new = (count, int(capacity))
+
+    def __enter__(self):
+        global _DYN
+        self._old, _DYN = _DYN, self._new
+        return self
+
+    def __exit__(self, *exc):
+        global _DYN
+        _DYN = self._old
+        return False
+
+
+def dyn_ptr(rows):
+    """n_dyn for a launch over `rows` rows: the live-count pointer when `rows` is the capacity of the active dynamic_rows
+    block, else None (launches over other row counts - graphs, dictionary rows - are static)."""
+    if _DYN is not None and int(rows) == _DYN[1]:
+        return _DYN[0].data_ptr()
+    return None
+
+
+def refuse_dynamic_rows(what, rows):
+    if _DYN is not None and int(rows) == _DYN[1]:
+        raise _lib.KpgnnError(f"{what} has no dynamic row count (n_dyn): run this configuration on exact-shape batches")
+
+
 def _last_contig(t):
     """[N,K,D] view with unit innermost stride (copy only if the caller handed something exotic)."""
     return t if t.stride(-1) == 1 else t.contiguous()
@@ -202,6 +240,7 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     dev = (x if x is not None else xs[0]).device
     d = _lib.AggFwdDesc()
     d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
+    d.n_dyn = dyn_ptr(N)
     use_tables = table0 is not None
     d.use_tables = 1 if use_tables else 0
     d.n_code0 = table0.shape[0] if use_tables else 0
@@ -258,6 +297,7 @@ def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, s
     bf16 = g.dtype == torch.bfloat16      # KPGNN_STORE_BF16: g rows are bf16, gx stays fp32
     d = _lib.AggBwdDesc()
     d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, mode
+    d.n_dyn = dyn_ptr(N)
     d.storage = 1 if bf16 else 0
     d.use_tables = 1 if want_tables else 0
     d.n_code0, d.n_codek = n_code0, n_codek
@@ -329,10 +369,12 @@ def dict_tile_pack(csr, uid):
     cache = csr._dict_packs
     key = (uid.data_ptr(), kf, uid.shape[0])
     hit = cache.get(key)
-    if hit is None:
+    # (a StaticBatch refills `uid` in place: under dynamic_rows the list is rebuilt by every call - into the same buffer, so a
+    #  captured graph refreshes it at every replay)
+    if hit is None or dyn_ptr(uid.shape[0]) is not None:
         N = uid.shape[0]
         tiles = (N + csr.nodes_per_tile - 1) // csr.nodes_per_tile
-        pack = torch.empty((tiles, 64), dtype=torch.int32, device=uid.device)
+        pack = hit[0] if hit is not None else torch.empty((tiles, 64), dtype=torch.int32, device=uid.device)
         with torch.cuda.device(uid.device):
             _lib.check(_lib.load().kpgnn_dict_tile_pack(uid.data_ptr(), kf, N, kf, csr.nodes_per_tile, pack.data_ptr(),
                                                         _stream(uid)), "kpgnn_dict_tile_pack")
@@ -356,6 +398,7 @@ def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     theta = theta.contiguous()
     d = _lib.DictGradDesc()
     d.N, d.K, d.D, d.n_dict = N, K, D, n_dict
+    d.n_dyn = dyn_ptr(N)
     d.uid, d.uid_stride, d.theta, d.gh = uid.data_ptr(), uid.stride(0), theta.data_ptr(), gh.data_ptr()
     dom = getattr(uid, "_kp_dom", None)          # [K] int32: the designated (most frequent) id per hop, if the caller has it
     if dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == dev:
@@ -394,6 +437,7 @@ def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, the
         return None
     d = _lib.TableGradDesc()
     d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n0, nk
+    d.n_dyn = dyn_ptr(N)
     d.n_dict = n_dict
     d.dict_src = 0 if n_dict == 0 else (1 if theta is not None else 2)
     d.kernel = kernel
@@ -469,6 +513,7 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
         return None
     d = _lib.TableGradDesc()
     d.N, d.K, d.D, d.nodes_per_tile, d.n_code0, d.n_codek = N, K, D, csr.nodes_per_tile, n_code0, nk
+    d.n_dyn = dyn_ptr(N)
     if dict_rows > 0:
         gd = torch.empty((dict_rows, D), dtype=torch.float32, device=dev) if gdict_acc is None else gdict_acc
         d.n_dict, d.dict_src, d.uid, d.uid_stride, d.gdict = dict_rows, 1, uid.data_ptr(), uid.stride(0), gd.data_ptr()
@@ -529,6 +574,7 @@ def combine_bwd_raw(mode, pre, gout, theta, periph, ptab, uid, want_gtheta, want
     lib = _lib.load()
     N, K, D = pre.shape
     dev = pre.device
+    refuse_dynamic_rows("kpgnn_combine_bwd", N)
     d = _lib.CombineBwdDesc()
     d.N, d.K, d.D, d.mode = N, K, D, mode
     d.pre = pre.data_ptr()
@@ -785,6 +831,7 @@ class KHopAggregate(torch.autograd.Function):
             gtheta = galpha
         geps = None
         if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
+            refuse_dynamic_rows("the eps gradient (framework sum over rows)", g.shape[0])
             xe = x_saved
             if xbias is not None and xe.shape[1] > 1:
                 xe = torch.cat([xe[:, :1], xe[:, 1:] + xbias], dim=1)
@@ -907,6 +954,7 @@ class TableGatherSum(torch.autograd.Function):
         out = torch.empty((M, D), dtype=torch.float32, device=table.device)
         d = _lib.TgsDesc()
         d.M, d.C, d.D, d.R = M, C, D, R
+        d.n_dyn = dyn_ptr(M)
         d.idx, d.col_offset, d.table, d.bias = idx.data_ptr(), col_offset.data_ptr(), table.data_ptr(), _ptr(bias)
         d.out, d.out_stride = out.data_ptr(), out.stride(0)
         with torch.cuda.device(table.device):
@@ -928,11 +976,14 @@ class TableGatherSum(torch.autograd.Function):
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=gout.device)
         d = _lib.TgsDesc()
         d.M, d.C, d.D, d.R = M, C, D, R
+        d.n_dyn = dyn_ptr(M)
         d.idx, d.col_offset = idx.data_ptr(), col_offset.data_ptr()
         d.gout, d.gout_stride, d.gtable = gout.data_ptr(), gout.stride(0), gtable.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         with torch.cuda.device(gout.device):
             _lib.check(lib.kpgnn_table_gather_sum_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_table_gather_sum_bwd")
+        if ctx.has_bias:
+            refuse_dynamic_rows("the bias gradient of a table gather-sum (framework row sum)", M)
         gbias = gout.sum(0) if ctx.has_bias else None
         return gtable, gbias, None, None
 
@@ -1052,6 +1103,7 @@ class SegmentPool(torch.autograd.Function):
         out = torch.empty((num_graphs, D), dtype=torch.float32, device=x.device)
         d = _lib.PoolDesc()
         d.N, d.G, d.D, d.mode = N, num_graphs, D, 1 if mean else 0
+        d.n_dyn = dyn_ptr(N)
         d.graph_ptr, d.x, d.x_stride, d.out = ptr.data_ptr(), x.data_ptr(), x.stride(0), out.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(lib.kpgnn_segment_pool_fwd(ctypes.byref(d), _stream(x)), "kpgnn_segment_pool_fwd")
@@ -1068,6 +1120,7 @@ class SegmentPool(torch.autograd.Function):
         gx = torch.empty((N, D), dtype=torch.float32, device=gout.device)
         d = _lib.PoolDesc()
         d.N, d.G, d.D, d.mode = N, G, D, 1 if mean else 0
+        d.n_dyn = dyn_ptr(N)
         d.graph_ptr, d.batch, d.gout, d.gx, d.gx_stride = ptr.data_ptr(), batch.data_ptr(), gout.data_ptr(), gx.data_ptr(), D
         with torch.cuda.device(gout.device):
             _lib.check(lib.kpgnn_segment_pool_bwd(ctypes.byref(d), _stream(gout)), "kpgnn_segment_pool_bwd")

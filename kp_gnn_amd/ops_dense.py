@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, dyn_ptr, refuse_dynamic_rows
 
 
 # ------------------------------------------------------------------------------------------- column-statistics slots
@@ -91,6 +91,7 @@ class BatchNormAct(torch.autograd.Function):
         stats = torch.empty((2, C), dtype=torch.float32, device=dev)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, C, 1 if relu else 0, eps, momentum
+        d.n_dyn = dyn_ptr(N)
         d.x, d.x_stride = x.data_ptr(), x.stride(0)
         d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
         d.running_mean, d.running_var = _ptr(running_mean), _ptr(running_var)
@@ -124,6 +125,7 @@ class BatchNormAct(torch.autograd.Function):
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
         d = _lib.BnBwdDesc()
         d.N, d.C, d.relu = N, C, 1 if ctx.relu else 0
+        d.n_dyn = dyn_ptr(N)
         d.x, d.x_stride, d.dz, d.dz_stride = x.data_ptr(), x.stride(0), dz.data_ptr(), dz.stride(0)
         d.gamma, d.beta, d.mean, d.invstd = gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
         d.dx, d.dx_stride = dx.data_ptr(), dx.stride(0)
@@ -158,6 +160,7 @@ def _mfma_linear(x, w, bias, transposed=False):
     y = torch.empty((N, O), dtype=torch.float32, device=x.device)
     d = _lib.LinearDesc()
     d.N, d.O, d.I = N, O, I
+    d.n_dyn = dyn_ptr(N)
     d.w_transposed = 1 if transposed else 0
     d.x, d.x_stride, d.w, d.bias, d.y, d.y_stride = x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), y.stride(0)
     with torch.cuda.device(x.device):
@@ -178,6 +181,8 @@ class LinearWgrad(torch.autograd.Function):
         ctx.has_bias = bias is not None
         xc = x if x.stride(-1) == 1 else x.contiguous()
         y = _mfma_linear(xc, weight.contiguous(), bias)
+        if y is None:
+            refuse_dynamic_rows("nn.Linear outside the MFMA kernels' shapes", x.shape[0])
         return y if y is not None else F.linear(x, weight, bias)
 
     @staticmethod
@@ -201,6 +206,7 @@ class LinearWgrad(torch.autograd.Function):
         ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
         d = _lib.WgradDesc()
         d.N, d.O, d.I = N, O, I
+        d.n_dyn = dyn_ptr(N)
         d.dy, d.dy_stride, d.x, d.x_stride = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
         d.dw, d.db, d.workspace, d.workspace_bytes = dw.data_ptr(), _ptr(db), ws.data_ptr(), int(nb)
         with torch.cuda.device(dev):
@@ -214,6 +220,7 @@ def linear(x, lin):
             and lin.weight.shape[1] <= 256 and x.shape[0] >= 1024 and torch.is_grad_enabled()
             and lin.weight.requires_grad):
         return LinearWgrad.apply(x, lin.weight, lin.bias)
+    refuse_dynamic_rows("nn.Linear on the framework path", x.shape[0])
     return lin(x)
 
 
@@ -227,6 +234,7 @@ def batch_norm_act(x, bn, relu=False, residual=None):
         nbt = bn.num_batches_tracked if bn.track_running_stats else None   # incremented inside the stats kernel
         return BatchNormAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.eps), float(bn.momentum), relu, nbt,
                                   _column_stats_of(x))
+    refuse_dynamic_rows("BatchNorm on the framework path", x.shape[0])
     out = bn(x)
     if relu:
         out = F.relu(out)
@@ -239,6 +247,7 @@ def _lin_bn(lib, dev, **kw):
     d = _lib.LinearBnDesc()
     for k, v in kw.items():
         setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
+    d.n_dyn = dyn_ptr(kw["N"])
     with torch.cuda.device(dev):
         _lib.check(lib.kpgnn_linear_bn(ctypes.byref(d), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_linear_bn")
 
@@ -280,6 +289,7 @@ class FusedMLP(torch.autograd.Function):
                 num_batches_tracked=bn1.num_batches_tracked if track1 else None, out_slot=slot2)
         d = _lib.BnDesc()
         d.N, d.C, d.relu, d.eps, d.momentum = N, O, 1, float(bn2.eps), float(bn2.momentum)
+        d.n_dyn = dyn_ptr(N)
         d.x, d.x_stride, d.gamma, d.beta = y2.data_ptr(), O, g2.data_ptr(), be2.data_ptr()
         if bn2.track_running_stats:
             d.running_mean, d.running_var = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
@@ -330,6 +340,7 @@ class FusedMLP(torch.autograd.Function):
         gb = torch.empty((6, O), dtype=torch.float32, device=dev)      # dgamma2, dbeta2, dgamma1, dbeta1, dgammaO, dbetaO
         d = _lib.BnBwdDesc()
         d.N, d.C, d.relu = N, O, 1
+        d.n_dyn = dyn_ptr(N)
         d.x, d.x_stride, d.dz, d.dz_stride = y2.data_ptr(), O, dz.data_ptr(), O
         d.gamma, d.beta, d.mean, d.invstd = g2.data_ptr(), be2.data_ptr(), st[2].data_ptr(), st[3].data_ptr()
         d.stat_slot, d.reduce_only = slot2.data_ptr(), 1
@@ -354,6 +365,7 @@ class FusedMLP(torch.autograd.Function):
         db = torch.empty((2, O), dtype=torch.float32, device=dev)
         a, b = _lib.WgradDesc(), _lib.WgradDesc()
         a.N, a.O, a.I = N, O, O
+        a.n_dyn = b.n_dyn = dyn_ptr(N)
         a.dy, a.dy_stride, a.x, a.x_stride = dy2.data_ptr(), O, y1.data_ptr(), O
         a.dw, a.db = dw3.data_ptr(), db[0].data_ptr()
         a.x_mean, a.x_invstd, a.x_gamma, a.x_beta, a.x_relu = st[0].data_ptr(), st[1].data_ptr(), g1.data_ptr(), be1.data_ptr(), 1
@@ -455,6 +467,7 @@ class JKConcatLinear(torch.autograd.Function):
             y = torch.empty((N, O), dtype=torch.float32, device=weight.device)
             d = _lib.LinearGroupDesc()
             d.N, d.O, d.I, d.group = N, O, H, len(states)
+            d.n_dyn = dyn_ptr(N)
             for l, st in enumerate(states):
                 d.x[l] = st.data_ptr()
             d.x_stride, d.w, d.bias, d.y, d.relu = H, weight.data_ptr(), _ptr(bias), y.data_ptr(), 1
@@ -462,6 +475,7 @@ class JKConcatLinear(torch.autograd.Function):
                 _lib.check(lib.kpgnn_linear_group_fwd(ctypes.byref(d), _stream(y)), "kpgnn_linear_group_fwd")
             ctx.save_for_backward(weight, y, *states)
             return y
+        refuse_dynamic_rows("the jumping-knowledge projection outside the grouped-K kernels' shapes", states[0].shape[0])
         rep = torch.cat(states, dim=1)
         if bias is not None and hasattr(torch, "_addmm_activation"):
             # the library GEMM with the bias + ReLU epilogue fused (bitwise the same as addmm + relu_; 117 vs 128 us at [47k, 936])
@@ -486,6 +500,7 @@ class JKConcatLinear(torch.autograd.Function):
                 G = torch.empty((S, N, H), dtype=torch.float32, device=dev)
                 d = _lib.LinearDesc()
                 d.N, d.O, d.I = N, S * H, O
+                d.n_dyn = dyn_ptr(N)
                 d.x, d.x_stride, d.w, d.y, d.y_stride = dy.data_ptr(), O, weight.data_ptr(), G.data_ptr(), H
                 d.w_transposed, d.y_block_cols, d.y_block_stride = 1, H, N * H
                 d.x_mask = y.data_ptr()                       # dL/d(pre-activation) = dy where the saved output is > 0
@@ -498,6 +513,7 @@ class JKConcatLinear(torch.autograd.Function):
                     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                     q = _lib.WgradDesc()
                     q.N, q.O, q.I = N, O, H
+                    q.n_dyn = dyn_ptr(N)
                     q.dy, q.dy_stride, q.x, q.x_stride = dy.data_ptr(), O, states[0].data_ptr(), H
                     q.dy_mask = y.data_ptr()
                     q.dw, q.db, q.workspace, q.workspace_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb
@@ -548,6 +564,7 @@ class HopMlp(torch.autograd.Function):
         lib = _lib.load()
         s = s.contiguous()
         N, K, DI = s.shape
+        refuse_dynamic_rows("kpgnn_hop_mlp", N)
         DO = w1.shape[2]
         H = wc.shape[0] if wc is not None else 0
         dev = s.device

@@ -213,3 +213,102 @@ def test_collated_batch_trains_like_the_plain_batch():
     for n in g0:
         tol = 2e-4 * max(float(g0[n].abs().max()), 0.05 * gscale) + 1e-7
         assert float((g0[n] - g1[n]).abs().max()) <= tol, n
+
+
+def _plus_model(K, L, H, dev):
+    from kp_gnn_amd import body as B
+    from kp_gnn_amd.layers import make_gnn_layer
+    ns = argparse.Namespace(model_name="KPGINPlus", hidden_size=H, K=K, num_layer=L, num_hop1_edge=3, max_pe_num=50,
+                            combine="geometric", eps=0., train_eps=False, aggr="add")
+    torch.manual_seed(0)
+    gnn = B.GNNPlus(num_layer=L, gnn_layer=make_gnn_layer(ns), JK="concat", norm_type="Batch", init_emb=B.EmbeddingEncoder(21, H),
+                    residual=True, virtual_node=False, use_rd=False, num_hop1_edge=3, max_edge_count=50, max_hop_num=6,
+                    max_distance_count=50, drop_prob=0.0)
+    return B.GraphRegression(gnn, "sum").to(dev).train()
+
+
+def _step(model, batch):
+    from kp_gnn_amd.ops_dense import regression_loss_and_grad
+    score = model(batch)
+    loss, dscore = regression_loss_and_grad(score, batch.y, "l1")
+    params = [p for p in model.parameters() if p.requires_grad]
+    grads = torch.autograd.grad(score, params, grad_outputs=dscore, allow_unused=True)
+    return loss, score, [g if g is None else g.clone() for g in grads]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Bsz", [96, 256])
+def test_static_batch_dynamic_rows_equal_exact_shapes(Bsz):
+    """A StaticBatch (capacity-shaped tensors, live node count on the device, every launch bounded by n_dyn) gives the same
+    loss and gradients as the exact-shape batch of the same graphs - eagerly and from ONE captured hipGraph replayed on
+    different batches (different N, A, entry counts).  BatchNorm statistics, weight gradients, table gradients and the
+    readout all sum over rows: a single phantom row in any of them would show here."""
+    from kp_gnn_amd.dataset import KHopDataset
+    dev = torch.device("cuda:0")
+    raw = molecules(400, seed0=21)
+    K, L, H = 4, 4, 32
+    args = (K, 50, 6, 3, 50, 50, "spd")
+    ds = KHopDataset.from_collated(raw.collated(args), raw.node_ptr, dev)
+    model = _plus_model(K, L, H, dev)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sb = ds.static_batch(Bsz)          # (96 graphs: ~2.2k nodes, the small-batch kernel choices; 256: ~5.9k, the large-batch ones)
+    assert sb.N_cap > int(ds.h_nodes.mean() * Bsz)
+    rng = np.random.default_rng(3)
+    id_sets = [rng.permutation(400)[:Bsz] for _ in range(3)]
+
+    def reset():
+        model.load_state_dict(sd)          # (running statistics and num_batches_tracked included)
+
+    def check(got, ref, what):
+        (l0, s0, g0), (l1, s1, g1) = got, ref
+        assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-5), what
+        assert abs(float(l0) - float(l1)) <= 2e-5 * max(1.0, abs(float(l1))), what
+        gscale = max(float(g.abs().max()) for g in g1 if g is not None)
+        for a, b in zip(g0, g1):
+            assert (a is None) == (b is None), what
+            if a is not None:
+                tol = 1e-4 * max(float(b.abs().max()), 0.05 * gscale) + 1e-7
+                assert float((a - b).abs().max()) <= tol, (what, float((a - b).abs().max()), tol)
+
+    refs = []
+    for ids in id_sets:
+        reset()
+        l, s_, g = _step(model, ds.collate(ids))
+        refs.append((l.clone(), s_.detach().clone(), g))
+    del l, s_, g          # (a live autograd graph from another stream makes the engine synchronise streams inside a later capture)
+    # eager, dynamic rows
+    with sb.dynamic():
+        for ids, ref in zip(id_sets, refs):
+            reset()
+            sb.stage(ids)
+            sb.launch_collate()
+            l, s_, g = _step(model, sb.batch)
+            assert sb.live[0] < sb.N_cap
+            check((l, s_.detach(), g), ref, "eager static batch")
+        del l, s_, g
+        # one captured graph, replayed on every batch
+        reset()
+        sb.stage(id_sets[0])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sb.launch_collate()
+            _step(model, sb.batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sb.launch_collate()
+            out = _step(model, sb.batch)
+    for ids, ref in zip(id_sets, refs):
+        reset()
+        sb.stage(ids)
+        graph.replay()
+        torch.cuda.synchronize()
+        check((out[0], out[1].detach(), out[2]), ref, "replayed static batch")
+    # a batch that does not fit is refused on the host, before anything is launched
+    from kp_gnn_amd.dataset import CapacityError
+    big = np.argsort(-ds.h_nodes)[:Bsz]
+    if int(ds.h_nodes[big].sum()) > sb.N_cap:
+        with pytest.raises(CapacityError):
+            sb.stage(big)
