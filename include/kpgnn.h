@@ -364,6 +364,10 @@ typedef struct kpgnn_table_grad_desc {
     /* Optional (host pointer): one deferred reduction of an earlier call, added up by this call's finishing launch. */
     const kpgnn_reduce_job* pending;
     const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
+    /* Optional: an upper bound (>= 1) on the multiplicity of any single entry of tile_pack, when the caller knows it (0 = unknown).
+     * Below 64 no run of equal entries was cut, i.e. every (node, hop, code) has ONE entry: the fused kernel may then take the
+     * table gradients as a count-matrix product on the matrix cores (8-bit count cells, entry order irrelevant). */
+    int32_t max_multiplicity;
 } kpgnn_table_grad_desc;
 
 size_t kpgnn_table_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t nodes_per_tile,

@@ -63,6 +63,7 @@ class TableGradDesc(ctypes.Structure):
         ("fuse_workspace", c_vp), ("fuse_workspace_bytes", ctypes.c_size_t), ("accumulate_dict", c_i32),
         ("pending", c_vp),
         ("n_dyn", c_vp),
+        ("max_multiplicity", c_i32),
     ]
 
 

@@ -510,6 +510,215 @@ table_grad_kernel(TgParams p, int AS) {
         *reinterpret_cast<float2*>(p.f_gth + (((int64_t)blockIdx.x * wph + fsub) * K + fk) * D + c) = make_float2(gth_a, gth_b);
 }
 
+// ------------------------------------------------------------------------------------------------ fused combine backward + table gradients on the matrix cores
+// The walk above costs ~3.4 us per tile of 64 (node, hop) rows - a sequential, scalar-issue-bound pass over the tile's sorted
+// entry list - and with it the fused kernel sat at 0.22-0.26 of the HBM roofline, 60 % of its compute phase waiting for rows
+// of S it had no registers left to request earlier.  The same sums are a small matrix product per tile,
+//     T[c, :] += sum_r C[c, r] * g[r, :],     C[c, r] = number of pairs of row r = (hop, node) that carry code c,
+// C a 64 x 64 matrix of small integers (exact in bf16) and g fp32.  g is split three ways into bf16 pieces
+// (hi + mid + lo carry 24 mantissa bits), so C x g runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 12 MFMAs per wave
+// and tile instead of the walk, products exact, one fixed summation order (bitwise reproducible), error that of the fp32 fmaf
+// chain (scripts/ubench/ub_mfma_bf16_counts.hip: 1.6e-7 of sum |terms| against 1.7e-7).  The count matrix is filled with integer
+// LDS adds straight from the tile's entry list - in ANY order: the list no longer has to be sorted for this kernel.
+// Wave w computes hop w of the tile (g = theta[w] * gh[i] * gelu'(S[i,w]): written to global memory for the transposed gather
+// and, split, to LDS as MFMA B-operands); waves (mt, nt) = (w / 4, w % 4) own the 32 x 32 block of the 64 x 128 accumulator
+// table for the whole launch (16 registers), written to the slab once at the end.
+typedef __attribute__((ext_vector_type(8))) __bf16 tg_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float tg_f32x16;
+constexpr int kCntPitch = 72;      // bytes per code row of the count matrix: 64 rows + 8 (stride of 18 words: conflict-free 8-byte reads)
+
+__device__ __forceinline__ void tg_split3(const float (&x)[8], tg_bf16x8& hi, tg_bf16x8& mid, tg_bf16x8& lo) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const __bf16 h = (__bf16)x[n];
+        const float r1 = x[n] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[n] = h; mid[n] = m; lo[n] = (__bf16)r2;
+    }
+}
+
+__global__ void __launch_bounds__(kThreadsTG, 4)   // two blocks per CU: 128 VGPRs
+tg_fuse_mfma_kernel(TgParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tid = threadIdx.x;
+    const int D = p.D, K = p.K, R = p.n0 + p.nk;
+    const int c = lane * 2;
+    const bool col_ok = c < D;                       // D even: both columns or none
+    const int cc = col_ok ? c : 0;
+    const int PC = D + 1;                            // 16-byte items per row block of a plane; item D stays zero
+    uint4* planes = reinterpret_cast<uint4*>(lds);                                   // [3][8][PC]
+    uint8_t* cnt = reinterpret_cast<uint8_t*>(planes + 3 * 8 * PC);                  // [2][64][kCntPitch]
+    float* ghs = reinterpret_cast<float*>(cnt + 2 * 64 * kCntPitch);                 // [2][8][D]
+    float* ths = ghs + 16 * D;                                                       // [8][D]
+    float* ptl = ths + 8 * D;                                                        // [f_U][D]
+    for (int i = tid; i < 3 * 8 * PC; i += kThreadsTG) planes[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * 64 * kCntPitch / 4; i += kThreadsTG) reinterpret_cast<uint32_t*>(cnt)[i] = 0u;
+    for (int i = tid; i < p.f_U * D; i += kThreadsTG) ptl[i] = p.f_ptab[i];
+    for (int i = tid; i < 8 * D; i += kThreadsTG) ths[i] = (i / D) < K ? p.theta[i] : 0.f;
+    const int64_t num_tiles = ((int64_t)p.N + 7) / 8;
+    const int G = gridDim.x;
+    const bool fwave = w < K;
+    // ---- travelling state (requested one tile ahead): S rows of hop w, this wave's gh row, the tile's entries, its list window
+    float2 sp[8];
+    auto load_s_rows = [&](int64_t t2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t node = t2 * 8 + j;
+            sp[j] = make_float2(0.f, 0.f);
+            if (t2 < num_tiles && node < p.N && fwave && col_ok)
+                sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + w) * (int64_t)D + c);
+        }
+    };
+    auto load_gh = [&](int64_t t2) -> float2 {       // wave w stages the gh row of node w of tile t2
+        const int64_t node = t2 * 8 + w;
+        float2 v = make_float2(0.f, 0.f);
+        if (t2 < num_tiles && node < p.N && col_ok) v = *reinterpret_cast<const float2*>(p.gh + node * D + c);
+        return v;
+    };
+    auto load_fu = [&](int64_t t2) -> int {          // lane n < 8: dictionary id of (node n of tile t2, hop w)
+        int v = 0;
+        if (p.f_uid && lane < 8 && fwave && t2 < num_tiles && t2 * 8 + lane < p.N) v = p.f_uid[(t2 * 8 + lane) * p.f_uid_stride + w];
+        return v;
+    };
+    auto load_win = [&](int64_t t2, int& b, int& e) {
+        b = e = 0;
+        if (t2 < num_tiles) { b = p.tptr[t2]; e = p.tptr[t2 + 1]; }
+    };
+    auto load_ent = [&](int b, int e) -> uint32_t { return (b + tid < e) ? p.tpack[b + tid] : 0xFFFFFFFFu; };   // hop 63 == none
+    // count-matrix cell of an entry: byte offset, or -1
+    auto cell_of = [&](uint32_t e) -> int {
+        const int hop = (int)(e & 0x3Fu);
+        if (hop >= K) return -1;
+        const int vcc = (int)(e >> 15);                                   // table << 16 | code
+        const int row = (vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc;
+        return row * kCntPitch + hop * 8 + (int)((e >> 12) & 7u);
+    };
+    int64_t tl = blockIdx.x;
+    int cb, ce, nb, ne;                              // windows of this tile and the next
+    load_win(tl, cb, ce);
+    load_win(tl + G, nb, ne);
+    uint32_t ecur = load_ent(cb, ce);
+    load_s_rows(tl);
+    float2 ghv = load_gh(tl);
+    int fucur = load_fu(tl);
+    if (col_ok) *reinterpret_cast<float2*>(ghs + w * D + c) = ghv;       // buffer 0 = this tile's gh rows
+    ghv = load_gh(tl + G);
+    float th_a = 0.f, th_b = 0.f, gth_a = 0.f, gth_b = 0.f;
+    if (fwave && col_ok) { th_a = p.theta[w * D + c]; th_b = p.theta[w * D + c + 1]; }
+    tg_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const int mt = w >> 2, nt = w & 3, li = lane & 31, kg = lane >> 5;
+    int gbuf = 0, cbuf = 0;
+    uint32_t eprev = 0xFFFFFFFFu;
+    int pb = 0, pe = 0;                              // previous tile's window (its cells are cleared while this tile's are filled)
+    __syncthreads();
+    for (; tl < num_tiles; tl += G) {
+        uint8_t* cnow = cnt + cbuf * 64 * kCntPitch;
+        uint8_t* cold = cnt + (cbuf ^ 1) * 64 * kCntPitch;
+        // ---- requests for the next tile (entries of tile tl + G, window of tile tl + 2G)
+        const uint32_t enext = load_ent(nb, ne);
+        int n2b, n2e;
+        load_win(tl + 2 * (int64_t)G, n2b, n2e);
+        // ---- count matrix: clear the cells of the tile before, add this tile's entries (any order: integer adds)
+        {
+            int q = cell_of(eprev);
+            if (q >= 0) cold[q] = 0;
+            for (int i = pb + kThreadsTG + tid; i < pe; i += kThreadsTG) { q = cell_of(p.tpack[i]); if (q >= 0) cold[q] = 0; }
+            q = cell_of(ecur);
+            if (q >= 0) atomicAdd(reinterpret_cast<uint32_t*>(cnow) + (q >> 2), (((ecur >> 6) & 0x3Fu) + 1u) << (8 * (q & 3)));
+            for (int i = cb + kThreadsTG + tid; i < ce; i += kThreadsTG) {
+                const uint32_t e2 = p.tpack[i];
+                q = cell_of(e2);
+                if (q >= 0) atomicAdd(reinterpret_cast<uint32_t*>(cnow) + (q >> 2), (((e2 >> 6) & 0x3Fu) + 1u) << (8 * (q & 3)));
+            }
+        }
+        // ---- compute phase: g = theta[w] * gh[i] * gelu'(S[i, w]) for the 8 nodes of the tile (hop w)
+        if (w < 8 && col_ok) *reinterpret_cast<float2*>(ghs + ((gbuf ^ 1) * 8 + w) * D + c) = ghv;    // next tile's gh row
+        if (fwave) {
+            float ga[8], gb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t node = tl * 8 + j;
+                ga[j] = 0.f; gb[j] = 0.f;
+                if (node < p.N) {                                          // (wave-uniform)
+                    const float2 gh2 = *reinterpret_cast<const float2*>(ghs + (gbuf * 8 + j) * D + cc);
+                    float a0, a1;
+                    gelu_bwd2(sp[j].x, th_a * gh2.x, a0, ga[j]);
+                    gelu_bwd2(sp[j].y, th_b * gh2.y, a1, gb[j]);
+                    float2 pr = make_float2(0.f, 0.f);
+                    if (p.f_uid) pr = *reinterpret_cast<const float2*>(ptl + __builtin_amdgcn_readlane(fucur, j) * D + cc);
+                    gth_a = fmaf(gh2.x, a0 + pr.x, gth_a);
+                    gth_b = fmaf(gh2.y, a1 + pr.y, gth_b);
+                    if (col_ok) *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + w * p.f_g_sk + c) = make_float2(ga[j], gb[j]);
+                }
+            }
+            if (col_ok) {                           // the row block of hop w, split three ways, as MFMA B operands
+                tg_bf16x8 hi, mid, lo;
+                tg_split3(ga, hi, mid, lo);
+                planes[(0 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, hi);
+                planes[(1 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, mid);
+                planes[(2 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, lo);
+                tg_split3(gb, hi, mid, lo);
+                planes[(0 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, hi);
+                planes[(1 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, mid);
+                planes[(2 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, lo);
+            }
+        }
+        load_s_rows(tl + G);
+        ghv = load_gh(tl + 2 * (int64_t)G);
+        const int funext = load_fu(tl + G);
+        __syncthreads();
+        // ---- C x g on the matrix cores: wave (mt, nt) owns codes [32 mt, 32 mt + 32) x columns [32 nt, 32 nt + 32)
+        {
+            const int col = nt * 32 + li;
+            const int pc = col < D ? col : D;       // (item D of every row block is zero)
+            const uint8_t* crow = cnow + (mt * 32 + li) * kCntPitch + 8 * kg;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint2 cw = *reinterpret_cast<const uint2*>(crow + 16 * ks);
+                tg_bf16x8 a;
+                a[0] = (__bf16)(float)(cw.x & 0xFFu); a[1] = (__bf16)(float)((cw.x >> 8) & 0xFFu);
+                a[2] = (__bf16)(float)((cw.x >> 16) & 0xFFu); a[3] = (__bf16)(float)(cw.x >> 24);
+                a[4] = (__bf16)(float)(cw.y & 0xFFu); a[5] = (__bf16)(float)((cw.y >> 8) & 0xFFu);
+                a[6] = (__bf16)(float)((cw.y >> 16) & 0xFFu); a[7] = (__bf16)(float)(cw.y >> 24);
+                const int rb = 2 * ks + kg;
+                const tg_bf16x8 b2 = __builtin_bit_cast(tg_bf16x8, planes[(2 * 8 + rb) * PC + pc]);
+                const tg_bf16x8 b1 = __builtin_bit_cast(tg_bf16x8, planes[(1 * 8 + rb) * PC + pc]);
+                const tg_bf16x8 b0 = __builtin_bit_cast(tg_bf16x8, planes[(0 * 8 + rb) * PC + pc]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc, 0, 0, 0);     // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                             // planes and this count buffer are free again
+        eprev = ecur; pb = cb; pe = ce;
+        ecur = enext; cb = nb; ce = ne; nb = n2b; ne = n2e;
+        fucur = funext;
+        gbuf ^= 1; cbuf ^= 1;
+    }
+    // ---- this block's partial tables (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+    {
+        const int col = nt * 32 + li;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * kg;
+            if (row < R && col < D) p.slab[((int64_t)blockIdx.x * R + row) * D + col] = acc[v];
+        }
+    }
+    if (p.f_gth && fwave && col_ok)
+        *reinterpret_cast<float2*>(p.f_gth + ((int64_t)blockIdx.x * K + w) * D + c) = make_float2(gth_a, gth_b);
+}
+
+// LDS bytes of the kernel above
+inline size_t tg_fuse_mfma_lds(int D, int f_U) {
+    return (size_t)3 * 8 * (D + 1) * 16 + (size_t)2 * 64 * kCntPitch + sizeof(float) * ((size_t)16 * D + 8 * D + (size_t)f_U * D);
+}
+
 // Dictionary entries of every tile, sorted by dictionary row: pack[tile*64 + j] = uid << 8 | node_in_tile << 3 | hop.
 // One wave per tile; 64 keys are ranked by counting (a one-off per batch: the ids are data, not parameters).
 __global__ void __launch_bounds__(kWave)
@@ -799,7 +1008,26 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
                       (size_t)d->workspace_bytes, pl.ws_bytes);
         p.slab = (float*)d->workspace;
-        rc = p.K >= 5 ? launch_walk<2, false, false, true, true>(p, pl, s) : launch_walk<2, false, false, true, false>(p, pl, s);
+        // K >= 5 hops, no dictionary rows in the walk, <= 64 accumulator rows and every (row, code) multiplicity known to be below
+        // 64 (no run of the entry list was cut: the 8-bit count cells cannot overflow): the matrix-core kernel
+        const bool mfma = p.K >= 5 && p.U == 0 && p.n0 + p.nk <= 64 && d->max_multiplicity >= 1 && d->max_multiplicity < 64 &&
+                          tg_fuse_mfma_lds(p.D, p.f_U) <= (size_t)device_facts().lds_per_block && d->kernel != 1;
+        if (mfma) {
+            const size_t lds = tg_fuse_mfma_lds(p.D, p.f_U);
+            int per_cu = (int)((160 * 1024) / lds);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+            const int64_t num_tiles = ((int64_t)p.N + 7) / 8;
+            int64_t gx = (int64_t)device_facts().cu_count * per_cu;
+            if (gx > num_tiles) gx = num_tiles;
+            if (gx > pl.grid_x) gx = pl.grid_x;                  // (the workspace was sized for the walk's grid)
+            pl.grid_x = (int)(gx < 1 ? 1 : gx);
+            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tg_fuse_mfma_kernel, lds));
+            hipLaunchKernelGGL(tg_fuse_mfma_kernel, dim3(pl.grid_x), dim3(kThreadsTG), lds, s, p);
+            KPGNN_LAUNCH_CHECK("tg_fuse_mfma_kernel");
+            rc = KPGNN_OK;
+        } else {
+            rc = p.K >= 5 ? launch_walk<2, false, false, true, true>(p, pl, s) : launch_walk<2, false, false, true, false>(p, pl, s);
+        }
         if (rc != KPGNN_OK) return rc;
         ThetaFinish tf;
         tf.slab = nullptr; tf.nslab = 0; tf.alpha = d->fuse_alphas; tf.theta = d->theta; tf.K = d->K; tf.D = d->D;

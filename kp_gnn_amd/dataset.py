@@ -132,8 +132,10 @@ class KHopDataset:
         ds.col_dst, ds.col_src = cat("col_dst", torch.int32), cat("col_src", torch.int32)
         ds.code_dst, ds.code_src = cat("code_dst", torch.int16), cat("code_src", torch.int16)
         ds.has_entries = with_entry_lists
+        ds.max_mult = 0
         if with_entry_lists:
             ds.ent_rel, ds.ent = cat("ent_rel", torch.int32), cat("ent", torch.int32)
+            ds.max_mult = int(((ds.ent >> 6) & 63).max().item()) + 1 if ds.ent.numel() else 1     # largest entry multiplicity
         ds.max_code0, ds.max_codek = max0, maxk
         # per-graph counts (host) and their running sums (device, int64)
         ds.h_nodes = np.diff(node_ptr)
@@ -199,7 +201,7 @@ class KHopDataset:
             data["graph." + k] = v
         if self.pdict is not None:
             data.update(uid=self.uid, dict_rows=self.pdict.rows, dict_dominant=self.pdict.dominant)
-        meta = {"K": self.K, "G": self.G, "max_code0": self.max_code0, "max_codek": self.max_codek,
+        meta = {"K": self.K, "G": self.G, "max_code0": self.max_code0, "max_codek": self.max_codek, "max_mult": self.max_mult,
                 "index_bounds": dict(self.index_bounds), "h_edges": torch.from_numpy(self.h_edges),
                 "h_hop_pairs": torch.from_numpy(self.h_hop_pairs),
                 "dict": None if self.pdict is None else {"col_max": list(self.pdict.col_max), "T": self.pdict.T, "Hc": self.pdict.Hc}}
@@ -214,6 +216,7 @@ class KHopDataset:
         ds = KHopDataset()
         dev = ds.device = torch.device(device)
         ds.K, ds.G, ds.max_code0, ds.max_codek = meta["K"], meta["G"], meta["max_code0"], meta["max_codek"]
+        ds.max_mult = meta.get("max_mult", 0)
         for k in ("rowptr_dst", "rowptr_src", "col_dst", "col_src", "code_dst", "code_src"):
             setattr(ds, k, data[k].to(dev))
         ds.node_ptr, ds.pair_ptr = slices["node"].to(dev), slices["pair"].to(dev)
@@ -279,6 +282,7 @@ class KHopDataset:
         c = KHopCSR()
         c.N, c.K, c.A, c.device = N, K, A, dev
         c.max_code0, c.max_codek = self.max_code0, self.max_codek
+        c._max_mult = self.max_mult if self.has_entries else None
         c.rowptr_dst, c.rowptr_src = torch.empty(N * K + 1, **i32), torch.empty(N * K + 1, **i32)
         c.col_dst, c.col_src = torch.empty(max(A, 1), **i32), torch.empty(max(A, 1), **i32)
         c.code_dst = torch.empty(max(A, 1), dtype=torch.int16, device=dev)

@@ -23,7 +23,7 @@ class KHopCSR:
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
                  "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
-                 "_dict_packs", "_tile_lists", "_keep", "device")
+                 "_dict_packs", "_tile_lists", "_keep", "_max_mult", "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
 
@@ -32,6 +32,7 @@ class KHopCSR:
         self._apairs = {}
         self._dict_packs = {}   # ops.dict_tile_pack: uid-sorted dictionary entries per tile, keyed by the uid tensor
         self._tile_lists = {}   # tile_list(k): hop-prefix copies of (tile_ptr, tile_pack)
+        self._max_mult = None   # largest multiplicity of an entry of tile_pack (host int), once known
 
     def tile_list(self, k_active):
         """(tile_ptr, tile_pack) restricted to hops < k_active (kpgnn_tile_pack_filter): what kpgnn_table_grad walks for a
@@ -53,6 +54,20 @@ class KHopCSR:
                     scratch.data_ptr(), torch.cuda.current_stream().cuda_stream), "kpgnn_tile_pack_filter")
             hit = self._tile_lists[k_active] = (optr, opack)
         return hit
+
+    def max_multiplicity(self):
+        """Largest multiplicity of a single table-gradient entry (1..64), or 0 when it is not known and cannot be read back
+        now (inside a stream capture).  Below 64 no run of equal (node, hop, code) pairs was cut, so every cell of a tile's
+        count matrix holds at most 63: the condition of the matrix-core table-gradient kernel (kpgnn_table_grad_desc.
+        max_multiplicity).  One host sync per CSR object; batches collated from a KHopDataset inherit the dataset's value."""
+        if self._max_mult is None:
+            if self.tile_ptr is None or torch.cuda.is_current_stream_capturing():
+                return 0
+            n = self.tile_ptr[-1]
+            idx = torch.arange(self.tile_pack.numel(), device=self.tile_pack.device)
+            m = torch.where(idx < n, (self.tile_pack >> 6) & 63, torch.zeros_like(self.tile_pack))
+            self._max_mult = int(m.max().item()) + 1 if self.tile_pack.numel() else 1
+        return self._max_mult
 
     def active_pairs(self, k_active):
         """Number of active (edge,hop) pairs within the first k_active hops (== A for k_active == K).

@@ -71,14 +71,14 @@ def set_storage_dtype(dtype):
 
 def bf16_shadow(t):
     """bf16 copy of a hop state [N,D] for the gathers of later layers (made once per state, kept on the tensor)."""
-    sh = getattr(t, "_kp_bf16", None)
-    if sh is None:
-        sh = t.detach().to(torch.bfloat16).contiguous()
+    rec = getattr(t, "_kp_bf16", None)
+    if rec is None or rec[0] != t._version:      # (a state modified in place after its first reader gets a fresh shadow)
+        rec = (t._version, t.detach().to(torch.bfloat16).contiguous())
         try:
-            t._kp_bf16 = sh
+            t._kp_bf16 = rec
         except AttributeError:
             pass
-    return sh
+    return rec[1]
 
 
 def _ptr(t):
@@ -166,6 +166,7 @@ class deferred_reductions:
         global _pending_reduce
         if self._outer is None:
             jobs, _pending_reduce = _pending_reduce, None
+            _deferred_owners.clear()
             if jobs and exc[0] is None:
                 flush_reductions(jobs)
         return False
@@ -178,10 +179,28 @@ def flush_reductions(jobs):
         _lib.check(_lib.load().kpgnn_reduce_jobs(arr, len(jobs), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_reduce_jobs")
 
 
-def defer_reduce_job():
+_deferred_owners = set()      # data_ptr of the parameters whose gradient a queued job will write
+
+
+def defer_reduce_job(*params):
     """A fresh job slot when reductions are being deferred (the caller hands ctypes.byref(job) to a launch with a `defer`
-    field, then calls queue_reduce_job), else None."""
-    return _lib.ReduceJob() if _pending_reduce is not None else None
+    field, then calls queue_reduce_job), else None.
+    `params`: the parameters whose gradients the job will write.  A parameter that feeds TWO nodes (shared MLP weights, a
+    layer applied twice) has its two gradients summed by autograd as soon as both nodes have returned - before the block
+    ends - so a second job for a parameter that already has one is refused (None: the caller reduces at once) and everything
+    queued so far is run first: the sum then only ever reads finished gradients."""
+    if _pending_reduce is None:
+        return None
+    keys = {p.data_ptr() for p in params if p is not None}
+    if keys & _deferred_owners:
+        jobs = list(_pending_reduce)
+        del _pending_reduce[:]
+        _deferred_owners.clear()
+        if jobs:
+            flush_reductions(jobs)
+        return None
+    _deferred_owners.update(keys)
+    return _lib.ReduceJob()
 
 
 def queue_reduce_job(job, keep_alive):
@@ -523,6 +542,7 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
         d.accumulate_dict = 1
     tptr, tpack = csr.tile_list(K)
     d.tile_ptr, d.tile_pack = tptr.data_ptr(), tpack.data_ptr()
+    d.max_multiplicity = csr.max_multiplicity()      # (< 64: the matrix-core kernel may take the table gradients)
     gh = gh.contiguous()
     theta = theta.contiguous()
     d.theta, d.gh = theta.data_ptr(), gh.data_ptr()
@@ -845,12 +865,38 @@ class KHopAggregate(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def _backward_pass_id():
+    """Identity of the autograd backward pass that is executing (-1 outside one)."""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:  # pragma: no cover - older torch
+        return -1
+
+
 class _SlotGradCell:
-    """Gradient buffer of one state tensor that several layers read as a hop slot (see khop_aggregate)."""
-    __slots__ = ("buf",)
+    """Gradient buffer of one state tensor that several layers read as a hop slot (see khop_aggregate).
+
+    Cells carry part of d/dstate OUTSIDE autograd: a reader parks its share in `buf`, later readers (in backward order) add
+    to it in place and the state's last reader hands autograd the total and clears the cell.  That is only sound within ONE
+    backward pass.  A pruned or partial pass (`autograd.grad(score, some_params, retain_graph=True)`) may park a share that
+    no reader of ITS pass ever collects; the parked buffer is therefore tagged with the pass that wrote it
+    (torch._C._current_graph_task_id()) and reads from any other pass see an empty cell - a stale share is never added to
+    a later pass's gradient (tests/test_gpu_parity.py::test_gradient_cells_survive_a_partial_backward)."""
+    __slots__ = ("_buf", "_task")
 
     def __init__(self):
-        self.buf = None
+        self._buf, self._task = None, -1
+
+    @property
+    def buf(self):
+        if self._buf is not None and self._task != _backward_pass_id():
+            self._buf = None                # parked by another backward pass: stale
+        return self._buf
+
+    @buf.setter
+    def buf(self, v):
+        self._buf = v
+        self._task = _backward_pass_id() if v is not None else -1
 
 
 def state_cell(t):
@@ -1084,6 +1130,8 @@ def graph_ptr_of(batch, num_graphs):
                               "host sync); run one eager step on the batch before capturing")
     if batch.numel() > 1 and bool((batch[1:] < batch[:-1]).any().item()):
         raise ValueError("graph readout needs the nodes of every graph to be contiguous (sorted `batch`)")
+    if batch.numel() and (int(batch[-1].item()) >= num_graphs or int(batch[0].item()) < 0):
+        raise IndexError(f"graph readout: batch holds graph ids outside [0, {num_graphs})")
     ptr = torch.searchsorted(batch, torch.arange(num_graphs + 1, device=batch.device, dtype=batch.dtype)).to(torch.int32)
     try:
         setattr(batch, _GPTR, ((batch._version, num_graphs), ptr))
@@ -1130,6 +1178,13 @@ class SegmentPool(torch.autograd.Function):
 def segment_pool(x, batch, num_graphs, mean=False):
     """Sum / mean readout of [N,D] node rows per graph on the HIP kernels (fp32 device tensors, int64 sorted batch)."""
     _require_cuda(x, batch)
+    if x.shape[1] > 256:       # (kpgnn_segment_pool_* instantiates row widths up to 256 floats: wider rows take the framework's scatter)
+        refuse_dynamic_rows("graph readout of rows wider than 256", x.shape[0])
+        out = x.new_zeros((num_graphs, x.shape[1])).index_add_(0, batch.long(), x)
+        if mean:
+            cnt = x.new_zeros(num_graphs).index_add_(0, batch.long(), x.new_ones(batch.numel()))
+            out = out / cnt.clamp(min=1).unsqueeze(-1)
+        return out
     return SegmentPool.apply(x, batch.long() if batch.dtype != torch.int64 else batch, graph_ptr_of(batch, num_graphs), num_graphs, mean)
 
 

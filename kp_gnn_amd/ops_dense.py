@@ -378,7 +378,7 @@ class FusedMLP(torch.autograd.Function):
                 nb = 2 * int(lib.kpgnn_wgrad_workspace_bytes(O, O))
                 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                 a.workspace, a.workspace_bytes = ws.data_ptr(), nb
-                job = ops.defer_reduce_job()          # (inside ops.deferred_reductions(): the reduce rides with a later launch)
+                job = ops.defer_reduce_job(w0, w3)    # (inside ops.deferred_reductions(): the reduce rides with a later launch)
                 if job is not None:
                     a.defer = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
                 _lib.check(lib.kpgnn_linear_wgrad_pair(ctypes.byref(a), ctypes.byref(b), _stream(h)), "kpgnn_linear_wgrad_pair")
@@ -518,7 +518,7 @@ class JKConcatLinear(torch.autograd.Function):
                     q.dy_mask = y.data_ptr()
                     q.dw, q.db, q.workspace, q.workspace_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb
                     xs = (ctypes.c_void_p * S)(*[st.data_ptr() for st in states])
-                    job = ops.defer_reduce_job()           # (inside ops.deferred_reductions(): the reduce rides with a later launch)
+                    job = ops.defer_reduce_job(weight)     # (inside ops.deferred_reductions(): the reduce rides with a later launch)
                     if job is not None:
                         q.defer = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
                     _lib.check(lib.kpgnn_linear_wgrad_group(ctypes.byref(q), xs, S, _stream(dy)), "kpgnn_linear_wgrad_group")

@@ -182,7 +182,16 @@ def test_unequal_shards_sum_to_the_global_batch_gradient():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
-    res = out.get()               # (before the joins: a put of this size blocks until it is read)
+    # (read before the joins: a put of this size blocks until it is read - but never wait forever for a rank that died
+    #  before its put: poll with a deadline and watch the exit codes)
+    import time
+    deadline = time.time() + 180
+    while out.empty():
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        assert not dead, f"a rank exited with {dead} before reporting"
+        assert time.time() < deadline, "no result from rank 0 within 180 s"
+        time.sleep(0.05)
+    res = out.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

@@ -1064,7 +1064,11 @@ def test_dict_grad_matches_index_add_bitwise(N, k_act, D, U):
 
 
 @pytest.mark.parametrize("N,k_act,D,in_walk", [(1237, 8, 104, False), (1237, 8, 104, True), (3001, 3, 104, True), (515, 1, 64, False),
-                                                (800, 5, 96, True), (64, 2, 24, True)])
+                                                (800, 5, 96, True), (64, 2, 24, True),
+                                                # the matrix-core kernel (k >= 5, no dictionary rows in the walk): partial last tile,
+                                                # D below / at the 128-column accumulator, a single tile
+                                                (4099, 8, 104, False), (2000, 6, 64, False), (777, 5, 128, False), (1237, 7, 26, False),
+                                                (5, 8, 104, False)])
 def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk):
     """kpgnn_table_grad with the combine backward fused in (KP-GIN+ path) against kpgnn_combine_bwd + kpgnn_table_grad run one
     after the other on the same inputs: dL/dS, the theta gradient and d/dalphas, both edge-code tables and (in_walk) the
@@ -1095,6 +1099,8 @@ def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk)
     r2 = ops.combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, 6, 6, want_gtheta=True, alphas=alphas,
                                     dict_rows=U if in_walk else 0)
     assert r is not None
+    if k_act >= 5 and not in_walk:
+        assert 1 <= csr.max_multiplicity() < 64       # (the condition of the matrix-core kernel: it is the one that ran)
     for a, b in zip(r[:1] + (r[1][0], r[1][1]) + r[2:], r2[:1] + (r2[1][0], r2[1][1]) + r2[2:]):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), "fused kernel is not bitwise repeatable"
     _close(r[0], g_ref.cpu(), "g", rtol=1e-5, atol=1e-6)
@@ -1286,7 +1292,6 @@ def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     if follow_norm == "fused_cell":
         from kp_gnn_amd import ops
         cell = ops.state_cell(rd)
-        cell.buf = torch.full((N, O), 0.25, device=dev)          # (a later reader's share, already parked)
     post = (norm_hip, rd) if follow_norm in ("fused", "fused_cell") else None
     outd = mlp_linear_bn_relu_x2(hip, xd, emit_out_stats=bool(follow_norm), post_norm=post)
     node = outd.grad_fn
@@ -1296,6 +1301,13 @@ def test_fused_mlp_vs_torch(N, I, O, follow_norm):
         from kp_gnn_amd import ops_dense
         assert ops_dense._column_stats_of(outd) is not None      # ... and left its statistics for the next BatchNorm
         outd = batch_norm_act(outd, norm_hip, relu=False, residual=rd)
+    if cell is not None:
+        # a later reader's share, parked DURING the backward pass, before this node runs (a share parked by another pass - or
+        # outside one - counts as stale: ops._SlotGradCell)
+        def park(gr):
+            cell.buf = torch.full((N, O), 0.25, device=dev)
+            return gr
+        outd.register_hook(park)
     (outd * w.to(dev)).sum().backward()
 
     def bn(t, m):
@@ -1310,7 +1322,7 @@ def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     _close(xd.grad, xr.grad, "dx", rtol=3e-4, atol=5e-5)
     if cell is not None:
         assert rd.grad is None
-        _close(cell.buf - 0.25, rr.grad, "dres (cell)")
+        _close(cell._buf - 0.25, rr.grad, "dres (cell)")
     elif follow_norm:
         _close(rd.grad, rr.grad, "dres")
     pr, ph = dict(ref.named_parameters()), dict(hip.named_parameters())
@@ -1664,3 +1676,68 @@ def test_shared_dictionary_gradient_cell_unfused_paths(D):
     a, b = run(True), run(False)
     for k in base:
         _close(a[k].grad, b[k].grad.cpu(), "grad " + k, rtol=2e-4, atol=2e-5)
+
+
+def test_gradient_cells_survive_a_partial_backward():
+    """The gradient cells (ops._SlotGradCell: parts of d/dstate carried outside autograd) are tagged with the backward pass
+    that parked them.  A partial pass - autograd.grad towards the LAST layer's parameters only, retain_graph=True - parks the
+    jumping-knowledge shares of every state and collects none of them; a full backward over the retained graph afterwards
+    must give exactly the gradients of a full backward alone (a stale share added twice would double them)."""
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    K, L, H = 3, 4, 32
+    model = _small_body("KPGINPlus", "geometric", K, L, H).to(dev).train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    b = synthetic_zinc_batch(40, seed0=3, K=K).to(dev)
+    b.build_csr()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+    def loss_of():
+        model.load_state_dict(sd)
+        model.zero_grad(set_to_none=True)
+        return (model(b).squeeze() - b.y.squeeze()).abs().mean()
+
+    loss_of().backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    loss = loss_of()
+    last = [p for n, p in model.named_parameters() if ".gnns.%d.mlp." % (L - 1) in n and p.requires_grad]
+    assert last
+    part = torch.autograd.grad(loss, last, retain_graph=True)
+    loss.backward()
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert got.keys() == ref.keys() and set(got) <= set(names)
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), (n, float((got[n] - ref[n]).abs().max()))
+    for g, p in zip(part, last):
+        assert torch.equal(g, p.grad)
+
+
+def test_deferred_reductions_with_a_weight_shared_by_two_nodes():
+    """Inside ops.deferred_reductions() a weight-gradient reduce normally waits for a later launch; a parameter that feeds
+    TWO nodes has its two gradients summed by autograd before the block ends, so its second job is not deferred and the queue
+    is flushed first (ops.defer_reduce_job): the summed gradient equals the plain run's."""
+    import torch.nn as nn
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.ops_dense import mlp_linear_bn_relu_x2
+    dev = _dev()
+    H, N = 32, 3000
+    torch.manual_seed(0)
+    mlp = nn.Sequential(nn.Linear(H, H), nn.BatchNorm1d(H), nn.ReLU(), nn.Linear(H, H), nn.BatchNorm1d(H), nn.ReLU()).to(dev).train()
+    x = torch.randn(N, H, device=dev)
+    params = [p for p in mlp.parameters()]
+
+    def run(deferred):
+        h = mlp_linear_bn_relu_x2(mlp, x)
+        out = mlp_linear_bn_relu_x2(mlp, h)           # the same Linears again
+        loss = out.square().mean()
+        if deferred:
+            with ops.deferred_reductions():
+                g = torch.autograd.grad(loss, params)
+        else:
+            g = torch.autograd.grad(loss, params)
+        torch.cuda.synchronize()
+        return g
+
+    a, b = run(True), run(False)
+    for ga, gb, p in zip(a, b, params):
+        assert torch.equal(ga, gb), tuple(p.shape)
