@@ -538,6 +538,11 @@ __device__ __forceinline__ void tg_split3(const float (&x)[8], tg_bf16x8& hi, tg
     }
 }
 
+// SUB = 8 / pow2ceil(K) tiles of 8 nodes form one SUPER-TILE of 64 (hop, node) rows whatever K is (K = 1: 64 nodes, K = 2: 32,
+// K = 3, 4: 16, K >= 5: 8), so that the early layers of a KP-GIN+ stack (few hops) do not pay two barriers for 8 rows.  Wave w
+// computes the 8 nodes of sub-tile w % SUB at hop w / SUB = row block w of the B planes; count-matrix row of an entry =
+// hop * 8 SUB + 8 sub + node_in_tile, its sub-tile read off the list windows of the super-tile's tiles.
+template <int SUB>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // two blocks per CU: 128 VGPRs
 tg_fuse_mfma_kernel(TgParams p) {
     p.N = live_rows(p.N, p.n_dyn);
@@ -552,112 +557,113 @@ tg_fuse_mfma_kernel(TgParams p) {
     const int PC = D + 1;                            // 16-byte items per row block of a plane; item D stays zero
     uint4* planes = reinterpret_cast<uint4*>(lds);                                   // [3][8][PC]
     uint8_t* cnt = reinterpret_cast<uint8_t*>(planes + 3 * 8 * PC);                  // [2][64][kCntPitch]
-    float* ghs = reinterpret_cast<float*>(cnt + 2 * 64 * kCntPitch);                 // [2][8][D]
-    float* ths = ghs + 16 * D;                                                       // [8][D]
-    float* ptl = ths + 8 * D;                                                        // [f_U][D]
+    float* ptl = reinterpret_cast<float*>(cnt + 2 * 64 * kCntPitch);                 // [f_U][D]
     for (int i = tid; i < 3 * 8 * PC; i += kThreadsTG) planes[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * 64 * kCntPitch / 4; i += kThreadsTG) reinterpret_cast<uint32_t*>(cnt)[i] = 0u;
     for (int i = tid; i < p.f_U * D; i += kThreadsTG) ptl[i] = p.f_ptab[i];
-    for (int i = tid; i < 8 * D; i += kThreadsTG) ths[i] = (i / D) < K ? p.theta[i] : 0.f;
     const int64_t num_tiles = ((int64_t)p.N + 7) / 8;
+    const int64_t num_super = (num_tiles + SUB - 1) / SUB;
     const int G = gridDim.x;
-    const bool fwave = w < K;
-    // ---- travelling state (requested one tile ahead): S rows of hop w, this wave's gh row, the tile's entries, its list window
-    float2 sp[8];
-    auto load_s_rows = [&](int64_t t2) {
+    const int hop = w / SUB, sub = w % SUB;          // this wave's hop and sub-tile
+    const bool fwave = hop < K;
+    // ---- travelling state (requested one super-tile ahead): S rows and gh rows of the wave's 8 nodes, the dictionary ids, the
+    //      super-tile's entries and the list windows of its tiles
+    float2 sp[8], ghp[8];
+    auto load_rows = [&](int64_t st) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t node = t2 * 8 + j;
-            sp[j] = make_float2(0.f, 0.f);
-            if (t2 < num_tiles && node < p.N && fwave && col_ok)
-                sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + w) * (int64_t)D + c);
+            const int64_t node = (st * SUB + sub) * 8 + j;
+            sp[j] = make_float2(0.f, 0.f); ghp[j] = sp[j];
+            if (st < num_super && node < p.N && fwave && col_ok) {
+                sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + hop) * (int64_t)D + c);
+                ghp[j] = *reinterpret_cast<const float2*>(p.gh + node * D + c);
+            }
         }
     };
-    auto load_gh = [&](int64_t t2) -> float2 {       // wave w stages the gh row of node w of tile t2
-        const int64_t node = t2 * 8 + w;
-        float2 v = make_float2(0.f, 0.f);
-        if (t2 < num_tiles && node < p.N && col_ok) v = *reinterpret_cast<const float2*>(p.gh + node * D + c);
-        return v;
-    };
-    auto load_fu = [&](int64_t t2) -> int {          // lane n < 8: dictionary id of (node n of tile t2, hop w)
+    auto load_fu = [&](int64_t st) -> int {          // lane n < 8: dictionary id of (node n of the wave's sub-tile, its hop)
         int v = 0;
-        if (p.f_uid && lane < 8 && fwave && t2 < num_tiles && t2 * 8 + lane < p.N) v = p.f_uid[(t2 * 8 + lane) * p.f_uid_stride + w];
+        const int64_t node = (st * SUB + sub) * 8 + lane;
+        if (p.f_uid && lane < 8 && fwave && st < num_super && node < p.N) v = p.f_uid[node * p.f_uid_stride + hop];
         return v;
     };
-    auto load_win = [&](int64_t t2, int& b, int& e) {
-        b = e = 0;
-        if (t2 < num_tiles) { b = p.tptr[t2]; e = p.tptr[t2 + 1]; }
+    auto load_win = [&](int64_t st) -> int {         // lane l <= SUB: first entry of tile st * SUB + l (clamped to the list's end)
+        int v = 0;
+        if (lane <= SUB && st < num_super) {
+            const int64_t t = st * SUB + lane;
+            v = p.tptr[t < num_tiles ? t : num_tiles];
+        }
+        return v;
     };
     auto load_ent = [&](int b, int e) -> uint32_t { return (b + tid < e) ? p.tpack[b + tid] : 0xFFFFFFFFu; };   // hop 63 == none
-    // count-matrix cell of an entry: byte offset, or -1
-    auto cell_of = [&](uint32_t e) -> int {
-        const int hop = (int)(e & 0x3Fu);
-        if (hop >= K) return -1;
+    // count-matrix cell of entry number i (value e) of a super-tile whose tile windows are `win`: byte offset, or -1
+    auto cell_of = [&](uint32_t e, int i, int win) -> int {
+        const int eh = (int)(e & 0x3Fu);
+        if (eh >= K) return -1;
+        int s2 = 0;
+#pragma unroll
+        for (int b = 1; b < SUB; ++b) s2 += (i >= __builtin_amdgcn_readlane(win, b)) ? 1 : 0;
         const int vcc = (int)(e >> 15);                                   // table << 16 | code
         const int row = (vcc >> 16) ? p.n0 + (vcc & 0xFFFF) : vcc;
-        return row * kCntPitch + hop * 8 + (int)((e >> 12) & 7u);
+        return row * kCntPitch + eh * (8 * SUB) + s2 * 8 + (int)((e >> 12) & 7u);
     };
-    int64_t tl = blockIdx.x;
-    int cb, ce, nb, ne;                              // windows of this tile and the next
-    load_win(tl, cb, ce);
-    load_win(tl + G, nb, ne);
-    uint32_t ecur = load_ent(cb, ce);
-    load_s_rows(tl);
-    float2 ghv = load_gh(tl);
-    int fucur = load_fu(tl);
-    if (col_ok) *reinterpret_cast<float2*>(ghs + w * D + c) = ghv;       // buffer 0 = this tile's gh rows
-    ghv = load_gh(tl + G);
+    int64_t st = blockIdx.x;
+    int wcur = load_win(st), wnext = load_win(st + G);
+    uint32_t ecur = load_ent(__builtin_amdgcn_readlane(wcur, 0), __builtin_amdgcn_readlane(wcur, SUB));
+    load_rows(st);
+    int fucur = load_fu(st);
     float th_a = 0.f, th_b = 0.f, gth_a = 0.f, gth_b = 0.f;
-    if (fwave && col_ok) { th_a = p.theta[w * D + c]; th_b = p.theta[w * D + c + 1]; }
+    if (fwave && col_ok) { th_a = p.theta[hop * D + c]; th_b = p.theta[hop * D + c + 1]; }
     tg_f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     const int mt = w >> 2, nt = w & 3, li = lane & 31, kg = lane >> 5;
-    int gbuf = 0, cbuf = 0;
+    int cbuf = 0;
     uint32_t eprev = 0xFFFFFFFFu;
-    int pb = 0, pe = 0;                              // previous tile's window (its cells are cleared while this tile's are filled)
+    int wprev = 0;                                   // previous super-tile's windows (its cells are cleared while this one's are filled)
     __syncthreads();
-    for (; tl < num_tiles; tl += G) {
+    // (Tried and dropped, all for a longer distance between a row request and its use: a second register set requested before the
+    //  compute phase - 35 spills at 128 registers per lane; refilling node j's registers as soon as node j is computed - 63; a
+    //  branch-free compute loop with clamped loads and dummy-slot stores - 32.)
+    for (; st < num_super; st += G) {
         uint8_t* cnow = cnt + cbuf * 64 * kCntPitch;
         uint8_t* cold = cnt + (cbuf ^ 1) * 64 * kCntPitch;
-        // ---- requests for the next tile (entries of tile tl + G, window of tile tl + 2G)
-        const uint32_t enext = load_ent(nb, ne);
-        int n2b, n2e;
-        load_win(tl + 2 * (int64_t)G, n2b, n2e);
-        // ---- count matrix: clear the cells of the tile before, add this tile's entries (any order: integer adds)
+        const int cb = __builtin_amdgcn_readlane(wcur, 0), ce = __builtin_amdgcn_readlane(wcur, SUB);
+        const int pb = __builtin_amdgcn_readlane(wprev, 0), pe = __builtin_amdgcn_readlane(wprev, SUB);
+        // ---- requests for the next super-tile (its entries; the windows of the one after)
+        const uint32_t enext = load_ent(__builtin_amdgcn_readlane(wnext, 0), __builtin_amdgcn_readlane(wnext, SUB));
+        const int wnext2 = load_win(st + 2 * (int64_t)G);
+        // ---- count matrix: clear the cells of the super-tile before, add this one's entries (any order: integer adds)
         {
-            int q = cell_of(eprev);
+            int q = cell_of(eprev, pb + tid, wprev);
             if (q >= 0) cold[q] = 0;
-            for (int i = pb + kThreadsTG + tid; i < pe; i += kThreadsTG) { q = cell_of(p.tpack[i]); if (q >= 0) cold[q] = 0; }
-            q = cell_of(ecur);
+            for (int i = pb + kThreadsTG + tid; i < pe; i += kThreadsTG) { q = cell_of(p.tpack[i], i, wprev); if (q >= 0) cold[q] = 0; }
+            q = cell_of(ecur, cb + tid, wcur);
             if (q >= 0) atomicAdd(reinterpret_cast<uint32_t*>(cnow) + (q >> 2), (((ecur >> 6) & 0x3Fu) + 1u) << (8 * (q & 3)));
             for (int i = cb + kThreadsTG + tid; i < ce; i += kThreadsTG) {
                 const uint32_t e2 = p.tpack[i];
-                q = cell_of(e2);
+                q = cell_of(e2, i, wcur);
                 if (q >= 0) atomicAdd(reinterpret_cast<uint32_t*>(cnow) + (q >> 2), (((e2 >> 6) & 0x3Fu) + 1u) << (8 * (q & 3)));
             }
         }
-        // ---- compute phase: g = theta[w] * gh[i] * gelu'(S[i, w]) for the 8 nodes of the tile (hop w)
-        if (w < 8 && col_ok) *reinterpret_cast<float2*>(ghs + ((gbuf ^ 1) * 8 + w) * D + c) = ghv;    // next tile's gh row
+        // ---- compute phase: g = theta[hop] * gh[i] * gelu'(S[i, hop]) for the wave's 8 nodes
         if (fwave) {
             float ga[8], gb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int64_t node = tl * 8 + j;
+                const int64_t node = (st * SUB + sub) * 8 + j;
                 ga[j] = 0.f; gb[j] = 0.f;
                 if (node < p.N) {                                          // (wave-uniform)
-                    const float2 gh2 = *reinterpret_cast<const float2*>(ghs + (gbuf * 8 + j) * D + cc);
                     float a0, a1;
-                    gelu_bwd2(sp[j].x, th_a * gh2.x, a0, ga[j]);
-                    gelu_bwd2(sp[j].y, th_b * gh2.y, a1, gb[j]);
+                    gelu_bwd2(sp[j].x, th_a * ghp[j].x, a0, ga[j]);
+                    gelu_bwd2(sp[j].y, th_b * ghp[j].y, a1, gb[j]);
                     float2 pr = make_float2(0.f, 0.f);
                     if (p.f_uid) pr = *reinterpret_cast<const float2*>(ptl + __builtin_amdgcn_readlane(fucur, j) * D + cc);
-                    gth_a = fmaf(gh2.x, a0 + pr.x, gth_a);
-                    gth_b = fmaf(gh2.y, a1 + pr.y, gth_b);
-                    if (col_ok) *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + w * p.f_g_sk + c) = make_float2(ga[j], gb[j]);
+                    gth_a = fmaf(ghp[j].x, a0 + pr.x, gth_a);
+                    gth_b = fmaf(ghp[j].y, a1 + pr.y, gth_b);
+                    if (col_ok) *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + hop * p.f_g_sk + c) = make_float2(ga[j], gb[j]);
                 }
             }
-            if (col_ok) {                           // the row block of hop w, split three ways, as MFMA B operands
+            if (col_ok) {                           // row block w, split three ways, as MFMA B operands
                 tg_bf16x8 hi, mid, lo;
                 tg_split3(ga, hi, mid, lo);
                 planes[(0 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, hi);
@@ -669,9 +675,8 @@ tg_fuse_mfma_kernel(TgParams p) {
                 planes[(2 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, lo);
             }
         }
-        load_s_rows(tl + G);
-        ghv = load_gh(tl + 2 * (int64_t)G);
-        const int funext = load_fu(tl + G);
+        load_rows(st + G);
+        const int funext = load_fu(st + G);
         __syncthreads();
         // ---- C x g on the matrix cores: wave (mt, nt) owns codes [32 mt, 32 mt + 32) x columns [32 nt, 32 nt + 32)
         {
@@ -696,10 +701,10 @@ tg_fuse_mfma_kernel(TgParams p) {
             }
         }
         __syncthreads();                             // planes and this count buffer are free again
-        eprev = ecur; pb = cb; pe = ce;
-        ecur = enext; cb = nb; ce = ne; nb = n2b; ne = n2e;
+        eprev = ecur; wprev = wcur;
+        ecur = enext; wcur = wnext; wnext = wnext2;
         fucur = funext;
-        gbuf ^= 1; cbuf ^= 1;
+        cbuf ^= 1;
     }
     // ---- this block's partial tables (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
     {
@@ -710,13 +715,13 @@ tg_fuse_mfma_kernel(TgParams p) {
             if (row < R && col < D) p.slab[((int64_t)blockIdx.x * R + row) * D + col] = acc[v];
         }
     }
-    if (p.f_gth && fwave && col_ok)
-        *reinterpret_cast<float2*>(p.f_gth + ((int64_t)blockIdx.x * K + w) * D + c) = make_float2(gth_a, gth_b);
+    if (p.f_gth && fwave && col_ok)                  // slab row = (block, sub-tile wave of the hop): gridDim.x * SUB partial [K,D] tables
+        *reinterpret_cast<float2*>(p.f_gth + (((int64_t)blockIdx.x * SUB + sub) * K + hop) * D + c) = make_float2(gth_a, gth_b);
 }
 
 // LDS bytes of the kernel above
 inline size_t tg_fuse_mfma_lds(int D, int f_U) {
-    return (size_t)3 * 8 * (D + 1) * 16 + (size_t)2 * 64 * kCntPitch + sizeof(float) * ((size_t)16 * D + 8 * D + (size_t)f_U * D);
+    return (size_t)3 * 8 * (D + 1) * 16 + (size_t)2 * 64 * kCntPitch + sizeof(float) * ((size_t)f_U * D);
 }
 
 // Dictionary entries of every tile, sorted by dictionary row: pack[tile*64 + j] = uid << 8 | node_in_tile << 3 | hop.
@@ -1008,21 +1013,26 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         KPGNN_REQUIRE(d->workspace && d->workspace_bytes >= pl.ws_bytes, "table_grad: workspace too small (%zu < %zu)",
                       (size_t)d->workspace_bytes, pl.ws_bytes);
         p.slab = (float*)d->workspace;
-        // K >= 5 hops, no dictionary rows in the walk, <= 64 accumulator rows and every (row, code) multiplicity known to be below
-        // 64 (no run of the entry list was cut: the 8-bit count cells cannot overflow): the matrix-core kernel
-        const bool mfma = p.K >= 5 && p.U == 0 && p.n0 + p.nk <= 64 && d->max_multiplicity >= 1 && d->max_multiplicity < 64 &&
+        // no dictionary rows in the walk, <= 64 accumulator rows and every (row, code) multiplicity known to be below 64 (no run of
+        // the entry list was cut: the 8-bit count cells cannot overflow): the matrix-core kernel
+        const bool mfma = p.U == 0 && p.n0 + p.nk <= 64 && d->max_multiplicity >= 1 && d->max_multiplicity < 64 &&
                           tg_fuse_mfma_lds(p.D, p.f_U) <= (size_t)device_facts().lds_per_block && d->kernel != 1;
         if (mfma) {
             const size_t lds = tg_fuse_mfma_lds(p.D, p.f_U);
             int per_cu = (int)((160 * 1024) / lds);
             per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-            const int64_t num_tiles = ((int64_t)p.N + 7) / 8;
+            int kp = 1;
+            while (kp < p.K) kp <<= 1;
+            const int sub = 8 / kp;                             // tiles of 8 nodes per super-tile of 64 rows
+            const int64_t num_super = (((int64_t)p.N + 7) / 8 + sub - 1) / sub;
             int64_t gx = (int64_t)device_facts().cu_count * per_cu;
-            if (gx > num_tiles) gx = num_tiles;
+            if (gx > num_super) gx = num_super;
             if (gx > pl.grid_x) gx = pl.grid_x;                  // (the workspace was sized for the walk's grid)
             pl.grid_x = (int)(gx < 1 ? 1 : gx);
-            KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tg_fuse_mfma_kernel, lds));
-            hipLaunchKernelGGL(tg_fuse_mfma_kernel, dim3(pl.grid_x), dim3(kThreadsTG), lds, s, p);
+#define KP_TGF(S) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tg_fuse_mfma_kernel<S>, lds)); \
+                       hipLaunchKernelGGL(tg_fuse_mfma_kernel<S>, dim3(pl.grid_x), dim3(kThreadsTG), lds, s, p); } while (0)
+            if (sub == 1) KP_TGF(1); else if (sub == 2) KP_TGF(2); else if (sub == 4) KP_TGF(4); else KP_TGF(8);
+#undef KP_TGF
             KPGNN_LAUNCH_CHECK("tg_fuse_mfma_kernel");
             rc = KPGNN_OK;
         } else {

@@ -1068,7 +1068,10 @@ def test_dict_grad_matches_index_add_bitwise(N, k_act, D, U):
                                                 # the matrix-core kernel (k >= 5, no dictionary rows in the walk): partial last tile,
                                                 # D below / at the 128-column accumulator, a single tile
                                                 (4099, 8, 104, False), (2000, 6, 64, False), (777, 5, 128, False), (1237, 7, 26, False),
-                                                (5, 8, 104, False)])
+                                                (5, 8, 104, False),
+                                                # ... with super-tiles of 2 / 4 / 8 tiles (k <= 4), node counts that leave partial super-tiles
+                                                (4099, 4, 104, False), (1237, 3, 104, False), (2003, 2, 64, False), (4101, 1, 104, False),
+                                                (9, 2, 32, False), (70, 1, 104, False)])
 def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk):
     """kpgnn_table_grad with the combine backward fused in (KP-GIN+ path) against kpgnn_combine_bwd + kpgnn_table_grad run one
     after the other on the same inputs: dL/dS, the theta gradient and d/dalphas, both edge-code tables and (in_walk) the
@@ -1099,7 +1102,7 @@ def test_fused_combine_table_grad_matches_separate_kernels(N, k_act, D, in_walk)
     r2 = ops.combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, 6, 6, want_gtheta=True, alphas=alphas,
                                     dict_rows=U if in_walk else 0)
     assert r is not None
-    if k_act >= 5 and not in_walk:
+    if not in_walk:
         assert 1 <= csr.max_multiplicity() < 64       # (the condition of the matrix-core kernel: it is the one that ran)
     for a, b in zip(r[:1] + (r[1][0], r[1][1]) + r[2:], r2[:1] + (r2[1][0], r2[1][1]) + r2[2:]):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), "fused kernel is not bitwise repeatable"
