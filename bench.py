@@ -186,20 +186,28 @@ def stream_copy_gbps(device):
     return 2 * x.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def traffic_key(args):
+    """Every flag that changes which kernels run (or how) is part of the key of a committed PMC traffic figure."""
+    key = f"{args.workload}|{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}"
+    for flag, tag in ((args.dtype != "f32", args.dtype), (args.dense_peripheral, "dense-peripheral"), (args.fresh_batches, "fresh-batches")):
+        if flag:
+            key += "|" + tag
+    return key
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the PMC counters.  A process cannot profile itself, so the figure comes
-    from the committed rocprofv3 --pmc passes of this same command (profiles/r02/pmc_traffic.json says how they were
+    from the committed rocprofv3 --pmc passes of this same command (profiles/r03/pmc_traffic.json says how they were
     collected and corrected).  It is only reported when the workload AND the kernel sources (csrc digest) are the ones
     that were profiled; otherwise null - a stale figure next to fresh timings would be worse than none."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    key = f"{args.workload}|{args.model}|B{args.batch}|K{args.K}|L{args.layers}|h{args.hidden}|{args.combine}" \
-        + ("" if args.dtype == "f32" else "|" + args.dtype)
+    path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+    key = traffic_key(args)
     try:
         with open(path) as fh:
             j = json.load(fh)
         if j.get("workload_key") == key and j.get("csrc_digest") == csrc_digest() and kernel in j.get("kernels", {}):
             return {"traffic": j["kernels"][kernel]["traffic_bytes_per_launch"],
-                    "traffic_source": "profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                    "traffic_source": "profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                       "this command on these kernel sources)"}
     except (OSError, ValueError):
         pass

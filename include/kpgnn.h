@@ -259,6 +259,12 @@ typedef struct kpgnn_agg_fwd_desc {
      * pointers; x_sn counts ELEMENTS. */
     int32_t storage;
     const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
+    /* Optional graph boundaries of the collated batch (device int32[num_graphs+1] node offsets, nodes of a graph contiguous as
+     * PyG's collate lays them out; max_graph_nodes >= the largest graph).  With them a mask-only aggregation (no tables, no
+     * peripheral features, no fused combine) whose largest graph's hop slab x[graph, hop, :] fits LDS is gathered FROM LDS: the
+     * slab is staged once per (graph, hop) block and every neighbour row comes from there - the kernel for dense K-hop
+     * neighbourhoods (run_simulation.py's 3-regular n = 1280 graphs: 582 pairs per node), where the plain gather is L2-bound. */
+    const int32_t* graph_ptr; int32_t num_graphs; int32_t max_graph_nodes;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

@@ -31,6 +31,11 @@ class KHopBatch:
     def build_csr(self):
         """Build the device CSR now and pin it to this batch's edge_index (layers pick it up)."""
         self.csr = KHopCSR.build(self.edge_index, self.edge_attr, self.num_nodes)
+        if self.batch is not None and self.num_graphs:
+            from .ops import graph_ptr_of
+            gp = graph_ptr_of(self.batch, self.num_graphs)
+            self.csr.graph_ptr = gp
+            self.csr.max_graph_nodes = int((gp[1:] - gp[:-1]).max().item()) if self.num_graphs > 0 else 0
         attach_khop_csr(self.edge_index, self.edge_attr, self.num_nodes, self.csr)
         return self.csr
 

@@ -721,6 +721,11 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         lds = sizeof(float) * (size_t)d->D * ((size_t)d->n_code0 + (size_t)(d->K > 1 ? d->n_codek : 0));
         tab = lds <= (size_t)kMaxLdsTableBytes ? 1 : 2;
     }
+    {   // dense neighbourhoods with the graph boundaries known: the graph's hop slab staged in LDS
+        bool handled = false;
+        const int rc = agg_lds_fwd(d, (hipStream_t)stream, &handled);
+        if (rc != KPGNN_OK || handled) return rc;
+    }
     {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
         bool handled = false;
         int rc = d->n_dyn ? KPGNN_OK : agg_narrow_fwd(d, (hipStream_t)stream, &handled);

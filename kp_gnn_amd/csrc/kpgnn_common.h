@@ -146,6 +146,8 @@ size_t table_grad_mfma_ws_bytes(int N, int K, int D, int NT, int n0, int nk, int
 // Element-per-thread aggregation for narrow rows (aggregate_narrow.hip): *handled tells whether the launch was done.
 int agg_narrow_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled);
 int agg_narrow_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled);
+// A graph's hop slab staged in LDS, for dense K-hop neighbourhoods (aggregate_lds.hip; needs desc.graph_ptr): *handled as above.
+int agg_lds_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled);
 // One block per node, one unit per hop, for small batches (aggregate_small.hip): *handled as above.
 int agg_small_fwd(const kpgnn_agg_fwd_desc* d, hipStream_t s, bool* handled);
 int agg_small_bwd(const kpgnn_agg_bwd_desc* d, hipStream_t s, bool* handled);

@@ -344,6 +344,7 @@ class KHopDataset:
         out.batch = batch_vec
         from .ops import _GPTR
         setattr(batch_vec, _GPTR, ((batch_vec._version, B), hdr[B:2 * B + 1]))
+        c.graph_ptr, c.max_graph_nodes = hdr[B:2 * B + 1], int(self.h_nodes.max()) if self.G else 0
         out.edge_index = torch.empty((2, 0), dtype=torch.int64, device=dev)
         out.edge_attr = torch.empty((0, K), dtype=torch.int64, device=dev)
         out.csr = c

@@ -23,7 +23,7 @@ class KHopCSR:
 
     __slots__ = ("N", "K", "E", "A", "rowptr_dst", "col_dst", "code_dst", "rowptr_src", "col_src", "code_src",
                  "tile_ptr", "tile_pack", "nodes_per_tile", "max_code0", "max_codek", "_dis", "_apairs",
-                 "_dict_packs", "_tile_lists", "_keep", "_max_mult", "device")
+                 "_dict_packs", "_tile_lists", "_keep", "_max_mult", "graph_ptr", "max_graph_nodes", "device")
 
     NODES_PER_TILE = 8  # destination nodes per LDS tile of the table-gradient kernel
 
@@ -33,6 +33,9 @@ class KHopCSR:
         self._dict_packs = {}   # ops.dict_tile_pack: uid-sorted dictionary entries per tile, keyed by the uid tensor
         self._tile_lists = {}   # tile_list(k): hop-prefix copies of (tile_ptr, tile_pack)
         self._max_mult = None   # largest multiplicity of an entry of tile_pack (host int), once known
+        # graph boundaries of the collated batch (int32 [G+1] node offsets) and the largest graph, when the batch builder knows
+        # them: dense neighbourhoods are then gathered from an LDS-staged hop slab (kpgnn_agg_fwd_desc.graph_ptr)
+        self.graph_ptr, self.max_graph_nodes = None, 0
 
     def tile_list(self, k_active):
         """(tile_ptr, tile_pack) restricted to hops < k_active (kpgnn_tile_pack_filter): what kpgnn_table_grad walks for a

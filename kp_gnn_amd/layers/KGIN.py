@@ -47,10 +47,16 @@ class KGINConv(KHopMessagePassing):
         x = self.proj(x).view(n, self.K, self.hidden_size)
         csr, k_act = get_khop_csr(edge_index, edge_attr, n)
         s = khop_aggregate(x, csr, k_act, MODE_GIN, eps=self.eps)             # x_n + (1+eps) x, mask only
-        h = s.transpose(0, 1)
-        h = F.relu(torch.baddbmm(self.hop_bias1.unsqueeze(1), h, self.hop_proj1))
-        h = F.relu(torch.baddbmm(self.hop_bias2.unsqueeze(1), h, self.hop_proj2))
-        out = self.combine_proj(h.transpose(0, 1).reshape(n, self.K * self.hidden_size))
+        from ..ops_dense import hop_mlp, hop_mlp_supported
+        if s.is_cuda and hop_mlp_supported(self.K, self.hidden_size, self.hidden_size):
+            # the per-hop 2-layer MLP (run_simulation.py:76-79) on the MFMA kernel the KP-GIN layers use: one launch
+            h2 = hop_mlp(s, self.hop_proj1, self.hop_bias1, self.hop_proj2, self.hop_bias2)      # N,K,h
+            out = self.combine_proj(h2.reshape(n, self.K * self.hidden_size))
+        else:
+            h = s.transpose(0, 1)
+            h = F.relu(torch.baddbmm(self.hop_bias1.unsqueeze(1), h, self.hop_proj1))
+            h = F.relu(torch.baddbmm(self.hop_bias2.unsqueeze(1), h, self.hop_proj2))
+            out = self.combine_proj(h.transpose(0, 1).reshape(n, self.K * self.hidden_size))
         if self.pool:
             from ..ops import segment_pool
             out = segment_pool(out, batch, int(batch[-1].item()) + 1)     # global_add_pool (run_simulation.py:83-84)

@@ -281,6 +281,11 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
         d.n_dict = ptab.shape[0]
     d.eps = _ptr(eps)
     d.xbias = _ptr(xbias)
+    # dense K-hop neighbourhoods (>= 12 pairs per (node, hop) on average) of a batch whose graph boundaries are known: the
+    # library may gather from an LDS-staged hop slab (mask-only aggregations; it checks the shape itself)
+    gp = getattr(csr, "graph_ptr", None)
+    if gp is not None and x is not None and not use_tables and csr.A >= 12 * max(csr.N * csr.K, 1) and d.n_dyn is None:
+        d.graph_ptr, d.num_graphs, d.max_graph_nodes = gp.data_ptr(), gp.numel() - 1, csr.max_graph_nodes
     pre = torch.empty((N, K, D), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev) if want_pre else None
     d.pre = _ptr(pre)
     d.storage = 1 if bf16 else 0

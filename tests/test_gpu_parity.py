@@ -1744,3 +1744,81 @@ def test_deferred_reductions_with_a_weight_shared_by_two_nodes():
     a, b = run(True), run(False)
     for ga, gb, p in zip(a, b, params):
         assert torch.equal(ga, gb), tuple(p.shape)
+
+
+@pytest.mark.parametrize("workload,model_name,K,L,H,graphs", [("qm9", "KPGIN", 6, 3, 24, 10), ("qm9", "KPGIN", 6, 8, 120, 6),
+                                                              ("zinc_gd16", "KPGINPrime", 16, 4, 96, 6)])
+def test_bench_workload_bodies_match_the_oracle(workload, model_name, K, L, H, graphs):
+    """The two bench.py workloads whose BODIES had no GPU parity test (their layers have reference goldens): the QM9 body
+    (QM9InputEncoder, no residual, MSE loss; train_qm9.py:84-115) and the K = 16 graph-diffusion KP-GIN' body (one KP-GIN layer
+    + GINE layers over the K-hop list; README.md:128), built exactly as bench.py builds them, against oracle/kp_model_oracle.py
+    on the CPU: score, loss and every parameter gradient."""
+    import argparse
+    import bench                                   # (the repo root is on sys.path: tests/conftest.py)
+    from oracle import kp_model_oracle as MO
+    dev = _dev()
+    wl = bench.WORKLOADS[workload]
+    args = argparse.Namespace(workload=workload, model=model_name, K=K, layers=L, hidden=H, batch=graphs, kernel=wl["kernel"],
+                              loss=wl["loss"], train=True, combine="geometric", dtype="f32")
+    model = bench.build_model(args, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    host = bench.make_batch(args, 4242, 4)
+    p = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k and not k.endswith(".eps")) else v.clone())
+         for k, v in sd.items()}
+    kind, layer_kind = {"KPGIN": ("GNN", "KPGIN"), "KPGINPrime": ("GNNPrime", "KPGIN")}[model_name]
+    ref = MO.graph_regression_forward(p, host.as_dict(), kind=kind, layer_kind=layer_kind, K=K, num_layer=L, combine_kind="geometric",
+                                      JK="concat", residual=workload != "qm9", training=True)
+    ref_loss = bench.loss_of(args, ref, host.y)
+    ref_loss.backward()
+    b = host.to(dev)
+    b.build_csr()
+    out = model(b)
+    loss = bench.loss_of(args, out, b.y)
+    loss.backward()
+    _close(out, ref, "score", rtol=2e-4, atol=2e-5)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-4 * max(1.0, abs(float(ref_loss)))
+    params = {n: q for n, q in model.named_parameters() if q.requires_grad}
+    ref_grads = {n: p[n].grad for n in params if p[n].grad is not None}
+    got = {n: q for n, q in params.items() if n in ref_grads or q.grad is not None}
+    for n, q in got.items():
+        if n not in ref_grads:
+            assert float(q.grad.abs().max()) == 0.0, n          # (e.g. the never-trained path-encoding table, Q1)
+    _close_param_grads({n: params[n] for n in ref_grads}, ref_grads, f"{workload} body", rtol=2e-3, atol=5e-5)
+
+
+@pytest.mark.parametrize("D,mode", [(16, "gin"), (16, "sum"), (4, "gin"), (32, "sum"), (64, "gin")])
+def test_aggregate_from_lds_staged_slab_equals_the_plain_gather(D, mode):
+    """Dense K-hop neighbourhoods (run_simulation.py's regular graphs, config 4) with the graph boundaries known: the mask-only
+    aggregation gathers from the graph's hop slab staged in LDS (csrc/aggregate_lds.hip).  Same pairs in the same order as the
+    plain gather: bitwise the same output - on graphs of different sizes, strided inputs included."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.batch import synthetic_regular_batch
+    dev = _dev()
+    b = synthetic_regular_batch(5, seed0=3, n=250, degree=3, K=6).to(dev)
+    b.build_csr()
+    csr = b.csr
+    assert csr.graph_ptr is not None and csr.max_graph_nodes == 250 and csr.A >= 12 * csr.N * csr.K
+    g = torch.Generator().manual_seed(D)
+    xfull = torch.randn(csr.N, csr.K, D + 4, generator=g).to(dev)
+    x = xfull[:, :, :D]                                              # (row and hop strides differ from the dense ones)
+    eps = torch.tensor([0.3], device=dev)
+    m = ops.MODE_GIN if mode == "gin" else ops.MODE_SUM
+    if D % 4 == 0 and (D + 4) % 4 == 0:
+        pass
+    got, _ = ops.aggregate_fwd_raw(csr, csr.K, m, x, None, None, None, eps if mode == "gin" else None, None, None, False)
+    gp, csr.graph_ptr = csr.graph_ptr, None                          # the same call without the boundaries: the plain kernels
+    try:
+        ref, _ = ops.aggregate_fwd_raw(csr, csr.K, m, x, None, None, None, eps if mode == "gin" else None, None, None, False)
+    finally:
+        csr.graph_ptr = gp
+    assert torch.equal(got, ref)
+    # ... and against the definition
+    rp, col = csr.rowptr_dst.cpu(), csr.col_dst.cpu()
+    xc = x.cpu()
+    want = torch.zeros(csr.N, csr.K, D)
+    seg = torch.repeat_interleave(torch.arange(csr.N * csr.K), (rp[1:] - rp[:-1]).long())
+    hop = seg % csr.K
+    want.view(-1, D).index_add_(0, seg, xc[col[:csr.A].long(), hop])
+    if mode == "gin":
+        want = want + 1.3 * xc
+    _close(got, want, "lds gather vs definition", rtol=1e-5, atol=1e-5)
