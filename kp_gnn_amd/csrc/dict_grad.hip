@@ -215,9 +215,12 @@ dict_grad_kernel(DgParams p) {
 
 struct DgPlan { int grid; size_t lds, ws_bytes; };
 
-bool dg_plan(int N, int K, int D, int U, DgPlan* pl) {
+// has_dom: the launch carries a designated id per hop - that path reads gh straight from L2 and needs no staging buffers
+// (only [kWavesDG + 1][D] floats for the block total), so larger dictionaries fit: U = 35 (a 10,000-molecule DATASET's distinct
+// tuples, dataset.py) at K = 8, D = 104 takes 120 KB instead of 170.
+bool dg_plan(int N, int K, int D, int U, DgPlan* pl, bool has_dom = false) {
     if (N < 1 || K < 1 || K > kWavesDG || D < 2 || D > 2 * kWave || (D & 1) || U < 1) return false;
-    pl->lds = sizeof(float) * ((size_t)U * K * D + 2 * (size_t)kChunk * D);
+    pl->lds = sizeof(float) * ((size_t)U * K * D + (has_dom ? (size_t)(kWavesDG + 1) * D : 2 * (size_t)kChunk * D));
     if (pl->lds > 160 * 1024) return false;
     int grid = device_facts().cu_count;
     const int chunks = (N + kChunk - 1) / kChunk;
@@ -234,7 +237,9 @@ using namespace kpgnn;
 
 extern "C" size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t n_dict) {
     DgPlan pl;
-    return dg_plan(N, K, D, n_dict, &pl) ? pl.ws_bytes : 0;
+    // (the workspace does not depend on the variant; a launch WITHOUT a designated id per hop whose staging buffers do not fit
+    //  is refused by kpgnn_dict_grad itself: KPGNN_ELIMIT)
+    return dg_plan(N, K, D, n_dict, &pl, true) ? pl.ws_bytes : 0;
 }
 
 extern "C" int32_t kpgnn_dict_grad_slabs(int32_t N) {
@@ -250,7 +255,7 @@ extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t str
     hipStream_t s = (hipStream_t)stream;
     if (d->N == 0) { if (d->defer_reduce) return fail(KPGNN_EINVAL, "dict_grad: defer_reduce with N == 0"); KPGNN_HIP_TRY(hipMemsetAsync(d->gdict, 0, sizeof(float) * (size_t)d->n_dict * d->D, s)); return KPGNN_OK; }
     DgPlan pl;
-    if (!dg_plan(d->N, d->K, d->D, d->n_dict, &pl))
+    if (!dg_plan(d->N, d->K, d->D, d->n_dict, &pl, d->dominant != nullptr))
         return fail(KPGNN_ELIMIT, "dict_grad: K=%d (<= 8), even D=%d (<= 128) and n_dict*K*D*4 + staging <= 160 KB of LDS needed "
                     "(n_dict=%d); use kpgnn_table_grad's dictionary path", d->K, d->D, d->n_dict);
     KPGNN_REQUIRE(d->uid && d->theta && d->gh && d->uid_stride >= d->K, "dict_grad: NULL uid/theta/gh or uid_stride < K");

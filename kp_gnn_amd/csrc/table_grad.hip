@@ -542,7 +542,10 @@ __device__ __forceinline__ void tg_split3(const float (&x)[8], tg_bf16x8& hi, tg
 // K = 3, 4: 16, K >= 5: 8), so that the early layers of a KP-GIN+ stack (few hops) do not pay two barriers for 8 rows.  Wave w
 // computes the 8 nodes of sub-tile w % SUB at hop w / SUB = row block w of the B planes; count-matrix row of an entry =
 // hop * 8 SUB + 8 sub + node_in_tile, its sub-tile read off the list windows of the super-tile's tiles.
-template <int SUB>
+// BF (KPGNN_STORE_BF16): S arrives and dL/dS leaves as bf16 rows (same element strides).  The table gradients are taken from
+// the ROUNDED dL/dS - the values the transposed gather will read - so g is one exact bf16 piece: one MFMA per k-step instead of
+// three.
+template <int SUB, bool BF>
 __global__ void __launch_bounds__(kThreadsTG, 4)   // two blocks per CU: 128 VGPRs
 tg_fuse_mfma_kernel(TgParams p) {
     p.N = live_rows(p.N, p.n_dyn);
@@ -575,7 +578,12 @@ tg_fuse_mfma_kernel(TgParams p) {
             const int64_t node = (st * SUB + sub) * 8 + j;
             sp[j] = make_float2(0.f, 0.f); ghp[j] = sp[j];
             if (st < num_super && node < p.N && fwave && col_ok) {
-                sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + hop) * (int64_t)D + c);
+                if (BF) {
+                    const uint32_t t = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(p.f_pre) + (node * K + hop) * (int64_t)D + c);
+                    sp[j] = make_float2(__uint_as_float(t << 16), __uint_as_float(t & 0xFFFF0000u));
+                } else {
+                    sp[j] = *reinterpret_cast<const float2*>(p.f_pre + (node * K + hop) * (int64_t)D + c);
+                }
                 ghp[j] = *reinterpret_cast<const float2*>(p.gh + node * D + c);
             }
         }
@@ -660,19 +668,29 @@ tg_fuse_mfma_kernel(TgParams p) {
                     if (p.f_uid) pr = *reinterpret_cast<const float2*>(ptl + __builtin_amdgcn_readlane(fucur, j) * D + cc);
                     gth_a = fmaf(ghp[j].x, a0 + pr.x, gth_a);
                     gth_b = fmaf(ghp[j].y, a1 + pr.y, gth_b);
-                    if (col_ok) *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + hop * p.f_g_sk + c) = make_float2(ga[j], gb[j]);
+                    if (BF) {
+                        const uint32_t b0 = f32_to_bf16_bits(ga[j]), b1 = f32_to_bf16_bits(gb[j]);
+                        if (col_ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.f_g) + node * p.f_g_sn + hop * p.f_g_sk + c) = b0 | (b1 << 16);
+                        ga[j] = __uint_as_float(b0 << 16); gb[j] = __uint_as_float(b1 << 16);     // what the gather will read
+                    } else if (col_ok) {
+                        *reinterpret_cast<float2*>(p.f_g + node * p.f_g_sn + hop * p.f_g_sk + c) = make_float2(ga[j], gb[j]);
+                    }
                 }
             }
-            if (col_ok) {                           // row block w, split three ways, as MFMA B operands
+            if (col_ok) {                           // row block w as MFMA B operands (fp32: split three ways; bf16: exact as is)
                 tg_bf16x8 hi, mid, lo;
                 tg_split3(ga, hi, mid, lo);
                 planes[(0 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, hi);
-                planes[(1 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, mid);
-                planes[(2 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, lo);
+                if (!BF) {
+                    planes[(1 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, mid);
+                    planes[(2 * 8 + w) * PC + c] = __builtin_bit_cast(uint4, lo);
+                }
                 tg_split3(gb, hi, mid, lo);
                 planes[(0 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, hi);
-                planes[(1 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, mid);
-                planes[(2 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, lo);
+                if (!BF) {
+                    planes[(1 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, mid);
+                    planes[(2 * 8 + w) * PC + c + 1] = __builtin_bit_cast(uint4, lo);
+                }
             }
         }
         load_rows(st + G);
@@ -692,11 +710,13 @@ tg_fuse_mfma_kernel(TgParams p) {
                 a[4] = (__bf16)(float)(cw.y & 0xFFu); a[5] = (__bf16)(float)((cw.y >> 8) & 0xFFu);
                 a[6] = (__bf16)(float)((cw.y >> 16) & 0xFFu); a[7] = (__bf16)(float)(cw.y >> 24);
                 const int rb = 2 * ks + kg;
-                const tg_bf16x8 b2 = __builtin_bit_cast(tg_bf16x8, planes[(2 * 8 + rb) * PC + pc]);
-                const tg_bf16x8 b1 = __builtin_bit_cast(tg_bf16x8, planes[(1 * 8 + rb) * PC + pc]);
+                if (!BF) {
+                    const tg_bf16x8 b2 = __builtin_bit_cast(tg_bf16x8, planes[(2 * 8 + rb) * PC + pc]);
+                    const tg_bf16x8 b1 = __builtin_bit_cast(tg_bf16x8, planes[(1 * 8 + rb) * PC + pc]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc, 0, 0, 0);     // smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc, 0, 0, 0);
+                }
                 const tg_bf16x8 b0 = __builtin_bit_cast(tg_bf16x8, planes[(0 * 8 + rb) * PC + pc]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc, 0, 0, 0);     // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc, 0, 0, 0);
             }
         }
@@ -987,9 +1007,10 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // Combine backward fused in: g = theta[k] * gh[i] * gelu'(S[i,k]) is computed per tile, written to fuse_g and walked
         // from LDS; the theta gradient leaves through fuse_workspace.  Edge-code tables only (the dictionary gradient has its
         // own kernel), fp32, one column block.
-        KPGNN_REQUIRE(edges && d->storage == KPGNN_STORE_F32 && d->K <= 8 && d->nodes_per_tile == 8 &&
+        const bool bf = d->storage == KPGNN_STORE_BF16;   // (bf16 S / dL/dS: the matrix-core kernel only)
+        KPGNN_REQUIRE(edges && (bf || d->storage == KPGNN_STORE_F32) && d->K <= 8 && d->nodes_per_tile == 8 &&
                       d->D % 2 == 0 && d->D <= 2 * kWave && d->theta && d->gh && d->fuse_g,
-                      "table_grad(fused combine): needs the edge lists, fp32, K <= 8, tiles of 8 nodes, even D <= 128, theta, gh, fuse_g");
+                      "table_grad(fused combine): needs the edge lists, K <= 8, tiles of 8 nodes, even D <= 128, theta, gh, fuse_g");
         KPGNN_REQUIRE(d->n_dict == 0 || (d->dict_src == 1 && d->dict_pack && d->gdict && d->dict_pack_K >= d->K && d->dict_pack_K <= 8),
                       "table_grad(fused combine): dictionary rows need dict_src 1, gdict and the uid-sorted list of kpgnn_dict_tile_pack");
         KPGNN_REQUIRE(!d->fuse_uid || (d->fuse_ptab && d->fuse_n_dict >= 1 && d->fuse_uid_stride >= d->K), "table_grad(fused combine): bad dictionary");
@@ -1017,6 +1038,9 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
         // the entry list was cut: the 8-bit count cells cannot overflow): the matrix-core kernel
         const bool mfma = p.U == 0 && p.n0 + p.nk <= 64 && d->max_multiplicity >= 1 && d->max_multiplicity < 64 &&
                           tg_fuse_mfma_lds(p.D, p.f_U) <= (size_t)device_facts().lds_per_block && d->kernel != 1;
+        if (bf && !mfma)
+            return fail(KPGNN_ELIMIT, "table_grad(fused combine): bf16 storage needs the matrix-core kernel (no dictionary rows in the "
+                        "walk, <= 64 table rows, max_multiplicity known and < 64)");
         if (mfma) {
             const size_t lds = tg_fuse_mfma_lds(p.D, p.f_U);
             int per_cu = (int)((160 * 1024) / lds);
@@ -1029,9 +1053,11 @@ extern "C" int kpgnn_table_grad(const kpgnn_table_grad_desc* d, kpgnn_stream_t s
             if (gx > num_super) gx = num_super;
             if (gx > pl.grid_x) gx = pl.grid_x;                  // (the workspace was sized for the walk's grid)
             pl.grid_x = (int)(gx < 1 ? 1 : gx);
-#define KP_TGF(S) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tg_fuse_mfma_kernel<S>, lds)); \
-                       hipLaunchKernelGGL(tg_fuse_mfma_kernel<S>, dim3(pl.grid_x), dim3(kThreadsTG), lds, s, p); } while (0)
+#define KP_TGF2(S, B) do { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)tg_fuse_mfma_kernel<S, B>, lds)); \
+                           hipLaunchKernelGGL((tg_fuse_mfma_kernel<S, B>), dim3(pl.grid_x), dim3(kThreadsTG), lds, s, p); } while (0)
+#define KP_TGF(S) do { if (bf) KP_TGF2(S, true); else KP_TGF2(S, false); } while (0)
             if (sub == 1) KP_TGF(1); else if (sub == 2) KP_TGF(2); else if (sub == 4) KP_TGF(4); else KP_TGF(8);
+#undef KP_TGF2
 #undef KP_TGF
             KPGNN_LAUNCH_CHECK("tg_fuse_mfma_kernel");
             rc = KPGNN_OK;

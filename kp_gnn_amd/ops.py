@@ -418,14 +418,17 @@ def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     if ws_bytes == 0 or uid.stride(1) != 1:
         return None
     dev = gh.device
+    dom = getattr(uid, "_kp_dom", None)          # [K] int32: the designated (most frequent) id per hop, if the caller has it
+    has_dom = dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == dev
+    if not has_dom and 4 * (n_dict * K * D + 2 * 64 * D) > 160 * 1024:
+        return None        # (without the hint the kernel stages gh in LDS next to the accumulator rows: this dictionary does not fit)
     gh = gh.contiguous()
     theta = theta.contiguous()
     d = _lib.DictGradDesc()
     d.N, d.K, d.D, d.n_dict = N, K, D, n_dict
     d.n_dyn = dyn_ptr(N)
     d.uid, d.uid_stride, d.theta, d.gh = uid.data_ptr(), uid.stride(0), theta.data_ptr(), gh.data_ptr()
-    dom = getattr(uid, "_kp_dom", None)          # [K] int32: the designated (most frequent) id per hop, if the caller has it
-    if dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == dev:
+    if has_dom:
         d.dominant = dom.data_ptr()
     gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
     ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
@@ -508,8 +511,13 @@ def _combine_table_grad_ok(csr, pre, table_rows=0, dict_rows=0):
     <= 160 KB (e.g. train_SR.py's max_pe_num = 1000 does not: those layers keep the separate kernels)."""
     N, K, D = pre.shape
     lds = 4 * (8 * K * D + (table_rows + 2 * dict_rows + 40) * D) + 64
-    return (pre.dtype == torch.float32 and K <= 8 and D % 2 == 0 and D <= 128 and csr.nodes_per_tile == 8
-            and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0 and lds <= 160 * 1024)
+    ok = (K <= 8 and D % 2 == 0 and D <= 128 and csr.nodes_per_tile == 8
+          and getattr(csr, "tile_ptr", None) is not None and pre.is_contiguous() and N > 0 and lds <= 160 * 1024)
+    if pre.dtype == torch.bfloat16:
+        # bf16 S / dL/dS (KPGNN_STORE_BF16): the matrix-core variant only - no dictionary rows riding along (large batches, where
+        # kpgnn_dict_grad takes them), <= 64 table rows, every entry multiplicity known to be below 64
+        return ok and N >= 4096 and table_rows <= 64 and 1 <= csr.max_multiplicity() < 64
+    return ok and pre.dtype == torch.float32
 
 
 def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, want_gtheta, alphas=None, extra=None,
@@ -528,6 +536,8 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
     if not _combine_table_grad_ok(csr, pre, n_code0 + nk, ptab.shape[0] if (ptab is not None and uid is not None) else 0):
         return None
     gd = None
+    if dict_rows > 0 and pre.dtype == torch.bfloat16:
+        return None                     # (bf16 storage: the matrix-core variant carries no dictionary rows)
     if dict_rows > 0:
         pack, kf = dict_tile_pack(csr, uid)
         if pack is None:
@@ -558,8 +568,9 @@ def combine_table_grad_raw(csr, pre, gh, theta, ptab, uid, n_code0, n_codek, wan
     d.workspace, d.workspace_bytes = ws.data_ptr(), int(ws_bytes)
     # dL/dS leaves hop-major ([K][N][D]: the transposed gather of kpgnn_aggregate_bwd then reads one contiguous [N,D] slab
     # per hop, like the forward's hop slots, instead of rows K*D floats apart - 1.5x of its bytes reached HBM that way)
-    g = torch.empty((K, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
+    g = torch.empty((K, N, D), dtype=pre.dtype, device=dev).permute(1, 0, 2)
     d.g_sn, d.g_sk = g.stride(0), g.stride(1)
+    d.storage = 1 if pre.dtype == torch.bfloat16 else 0
     d.fuse_pre, d.fuse_g = pre.data_ptr(), g.data_ptr()
     if uid is not None and ptab is not None:
         d.fuse_ptab, d.fuse_uid, d.fuse_uid_stride, d.fuse_n_dict = ptab.data_ptr(), uid.data_ptr(), uid.stride(0), ptab.shape[0]
