@@ -17,7 +17,9 @@ A "step" is one optimisation step (forward only for `regular`) on one pre-staged
 K-hop CSR resident in HBM before the timed region).  --fresh-batches: the reference's epoch instead (train_ZINC.py:224: a
 shuffled DataLoader, no batch is seen twice) - a dataset of --dataset-graphs pre-transformed graphs stays resident in HBM
 (kp_gnn_amd/dataset.py) and EVERY timed step first collates a new random subset of it (kpgnn_collate, inside the timed region).  N > 1: one process per GPU (torchrun), graphs sharded across
-ranks, model replicated, one RCCL all-reduce of the flat gradient bucket per step; weak scaling.
+ranks, model replicated, one RCCL all-reduce of the flat gradient bucket per step; weak scaling (--batch graphs per GPU).
+--scaling strong: --batch is ONE global batch, partitioned over the ranks by active pairs (dp.partition_by_pairs), each rank's
+mean loss weighted by its share of the graphs (dp.shard_loss_weight), gradients summed.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     HIP-event timing of the aggregation kernel launches vs the algorithmic bytes of SURVEY.md 8(d)
@@ -105,6 +107,9 @@ def fwd_bwd(args, model, batch, flat_grad):
     from kp_gnn_amd.ops_dense import regression_loss_and_grad
     score = model(batch)
     loss, dscore = regression_loss_and_grad(score, batch.y, args.loss)   # train_ZINC.py:42 / train_qm9.py:96, with its gradient
+    w = getattr(batch, "_loss_weight", None)
+    if w is not None:      # --scaling strong: this rank's share n_r / G of the global mean loss (dp.shard_loss_weight)
+        loss, dscore = loss * w, dscore * w
     params, views = dp.grad_views(model)
     from kp_gnn_amd import ops
     with ops.deferred_reductions():      # (gradients are read after the block: the weight-gradient reduces ride along)
@@ -128,7 +133,10 @@ def train_step(args, model, batch, opt, flat_grad, world, graph=None):
     else:
         out = fwd_bwd(args, model, batch, flat_grad)
     if args.train and not stepped:
-        dp.allreduce_mean(flat_grad, world)
+        if args.scaling == "strong":
+            dp.allreduce_sum(flat_grad, world)      # (unequal shards, losses pre-weighted: the sum IS the global-mean gradient)
+        else:
+            dp.allreduce_mean(flat_grad, world)
         opt.step()
     return out
 
@@ -286,6 +294,10 @@ def main():
                          "inside the timed region; launches are eager (batch shapes differ from step to step)")
     ap.add_argument("--dataset-graphs", type=int, default=10000, help="--fresh-batches: graphs per rank in the resident dataset "
                     "(10,000 = ZINC-12k's training split)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: --batch graphs PER GPU (the default line).  strong: --batch is ONE global batch, partitioned over the "
+                         "ranks by active (edge, hop) pairs (dp.partition_by_pairs), every rank's mean loss weighted by its share "
+                         "(dp.shard_loss_weight) and the gradients summed - the reference's DataParallel step on a fixed batch")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: all ranks use cuda:0")
@@ -297,6 +309,8 @@ def main():
     args.kernel, args.loss, args.train = wl["kernel"], wl["loss"], wl["train"]
     if args.workload == "regular":
         args.model = "KGIN"
+    if args.scaling == "strong" and (args.fresh_batches or not args.train):
+        raise SystemExit("--scaling strong partitions pre-staged global batches of a training workload")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -357,6 +371,22 @@ def main():
             state["pos"] += args.batch
             return ids
         batches = [dataset.collate(sampler()) for _ in range(args.num_batches)]   # warm-up / per-launch timing leg
+    elif args.scaling == "strong":
+        # ONE global batch per step, the same on every rank (shared seed); each rank keeps the graphs partition_by_pairs gives it
+        import numpy as np
+        from kp_gnn_amd.dataset import KHopDataset
+        if args.batch < world:
+            raise SystemExit("--scaling strong needs --batch >= the number of ranks")
+        shard_pairs = []
+        for i in range(args.num_batches):
+            host = make_batch(args, dp.shard_seed(0, args.num_batches, i, args.batch), threads)
+            ds = KHopDataset.from_collated(host, host.node_ptr, device)
+            shards = dp.partition_by_pairs(ds.h_pairs, world)
+            b = ds.collate(np.asarray(shards[rank], dtype=np.int64))
+            b._loss_weight = dp.shard_loss_weight(len(shards[rank]), args.batch)
+            shard_pairs.append([int(sum(int(ds.h_pairs[g]) for g in sh)) for sh in shards])
+            batches.append(b)
+            del ds, host
     else:
         for i in range(args.num_batches):  # each rank owns its shard of graphs (distinct seeds)
             seed0 = dp.shard_seed(rank, args.num_batches, i, args.batch)
@@ -429,7 +459,7 @@ def main():
             train_step(args, model, batches[i], opt, flat_grad, world, graphs[i])
         torch.cuda.synchronize()
     if rank == 0:
-        log(f"{args.warmup} warm-up steps done; launch mode: {'hipGraph replay' if graphs else 'eager'}")
+        log(f"{args.warmup} warm-up steps done; launch mode: {'hipGraph replay' if graphs else 'ONE static-shape hipGraph (collate + fwd + bwd)' if static_graph else 'eager'}")
     overflow_steps = 0
     if args.fresh_batches:
         from kp_gnn_amd.dataset import CapacityError
@@ -452,6 +482,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(elapsed, device, world)
+    if args.scaling == "strong" and world > 1:      # the global mean loss = the sum of the ranks' weighted means
+        out_t = out_t.clone()
+        torch.distributed.all_reduce(out_t)
     final = float(out_t.float().abs().mean().item()) if not args.train else float(out_t.item())
     if rank == 0:
         log(f"timed {args.steps} steps in {elapsed:.3f}s")
@@ -469,7 +502,8 @@ def main():
         ops.set_launch_timer(None)
 
     if rank == 0:
-        total_graphs = args.batch * world * args.steps
+        strong = args.scaling == "strong"
+        total_graphs = args.batch * (1 if strong else world) * args.steps
         b0 = batches[0]
         what = "fwd+bwd+Adam, " + ("L1" if args.loss == "l1" else "MSE") + " loss" if args.train else "forward only (eval, no grad)"
         desc = {"zinc": "ZINC-12k-shaped synthetic molecules", "qm9": "QM9-shaped synthetic molecules",
@@ -480,16 +514,19 @@ def main():
             "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 storage of the K-hop streams (hop-slot rows, S, dL/dS), f32 accumulate / parameters / states",
             "data": "synthetic",
             "config": {"workload": f"{desc}, {args.model} K={args.K} L={args.layers} h={args.hidden} kernel={args.kernel}"
                                    + (f" {args.combine} combine" if args.train else "") + f", {what}"
                                    + (", dense peripheral tensor" if args.dense_peripheral else ""),
-                       "graphs_per_gpu_per_step": args.batch, "global_batch": args.batch * world,
+                       "graphs_per_gpu_per_step": args.batch if not strong else round(args.batch / world, 1),
+                       "global_batch": args.batch * (1 if strong else world),
                        "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.csr.E),
                        "active_pairs_per_batch": int(b0.csr.A),
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}" + (" (one global batch partitioned by active pairs; rank 0's shard sizes are the "
+                                                       "nodes / pairs fields; pairs per rank, first batch: " + str(shard_pairs[0]) + ")"
+                                                       if strong else ""),
                        "launch": ("hipGraph replay of collate+fwd+bwd: ONE static-shape graph for all batches (capacity "
                                   f"{static.N_cap} nodes, live count on the device; {overflow_steps} eager overflow steps)") if static_graph
                        else ("hipGraph replay of fwd+bwd" if graphs else "eager"),

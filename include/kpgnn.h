@@ -159,6 +159,15 @@ int kpgnn_collate(const kpgnn_collate_desc* d, kpgnn_stream_t stream);
 int kpgnn_regression_loss(const float* score, const float* y, int64_t n, int32_t kind, float* loss, float* dscore,
                           kpgnn_stream_t stream);
 
+/* The graph regressor nn.Linear(hidden, 1) on the pooled graph rows (reference models/GraphRegression.py:17,46-51):
+ * score[g] = sum_c pooled[g][c] w[c] + bias[0] (bias may be NULL).  pooled: device [G, D] contiguous fp32; w: [D]; score: [G]. */
+int kpgnn_score_head_fwd(const float* pooled, const float* w, const float* bias, int64_t G, int32_t D, float* score,
+                         kpgnn_stream_t stream);
+/* Its backward in one launch: dpooled[g][c] = dscore[g] w[c] (NULL: skipped), dw[c] = sum_g dscore[g] pooled[g][c],
+ * db[0] = sum_g dscore[g] (NULL: skipped); fixed summation order (bitwise reproducible). */
+int kpgnn_score_head_bwd(const float* pooled, const float* w, const float* dscore, int64_t G, int32_t D, float* dpooled,
+                         float* dw, float* db, kpgnn_stream_t stream);
+
 /* One torch.optim.Adam step (amsgrad off, L2 weight_decay as in train_ZINC.py:244) over a flat bucket of n fp32
  * parameters with its gradient and the two moment buffers (all device, 16-B aligned, updated in place); step = 1 for the
  * first call.  Elementwise, so stepping the flat bucket of dp.py equals stepping the ~190 tensors one by one. */

@@ -257,6 +257,8 @@ SIGNATURES = {
     "kpgnn_tile_pack_prefixes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "kpgnn_collate": (ctypes.c_int, [ctypes.POINTER(CollateDesc), c_vp]),
     "kpgnn_regression_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "kpgnn_score_head_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "kpgnn_score_head_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_double, c_vp]),
     "kpgnn_reduce_jobs": (ctypes.c_int, [c_vp, c_i32, c_vp]),

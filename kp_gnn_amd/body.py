@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .layers.gine import GINEConv
 from .ops import DictPeripheral, embedding_rows, enc_tables, segment_pool, table_gather_sum
-from .ops_dense import JKConcatLinear, batch_norm_act
+from .ops_dense import JKConcatLinear, batch_norm_act, score_head
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
 
@@ -591,4 +591,4 @@ class GraphRegression(nn.Module):
 
     def forward(self, data):
         x = self.embedding_model(data)
-        return self.regressor(self.pool(x, data.batch, _get(data, "num_graphs"))).squeeze()
+        return score_head(self.pool(x, data.batch, _get(data, "num_graphs")), self.regressor).squeeze()

@@ -662,6 +662,46 @@ def geo_theta(alphas, K):
     return GeoTheta.apply(alphas, K)
 
 
+# ------------------------------------------------------------------------------------------- graph regressor
+class ScoreHead(torch.autograd.Function):
+    """nn.Linear(hidden, 1) on the pooled graph rows (reference models/GraphRegression.py:17,46-51) as one launch per pass
+    (kpgnn_score_head_fwd / _bwd) instead of two library GEMM launches of ~10.7 us and a bias reduce."""
+
+    @staticmethod
+    def forward(ctx, pooled, weight, bias):
+        p = pooled.contiguous()
+        w = weight.reshape(-1).contiguous()
+        G, D = p.shape
+        score = torch.empty((G, 1), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.load().kpgnn_score_head_fwd(p.data_ptr(), w.data_ptr(), _ptr(bias), G, D, score.data_ptr(), _stream(p)),
+                       "kpgnn_score_head_fwd")
+        ctx.save_for_backward(p, w)
+        ctx.has_bias = bias is not None
+        return score
+
+    @staticmethod
+    def backward(ctx, ds):
+        p, w = ctx.saved_tensors
+        G, D = p.shape
+        ds = ds.reshape(-1).contiguous()
+        dp_ = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((1, D), dtype=torch.float32, device=p.device)
+        db = torch.empty(1, dtype=torch.float32, device=p.device) if ctx.has_bias else None
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.load().kpgnn_score_head_bwd(p.data_ptr(), w.data_ptr(), ds.data_ptr(), G, D, _ptr(dp_), dw.data_ptr(),
+                                                        _ptr(db), _stream(p)), "kpgnn_score_head_bwd")
+        return dp_, dw, db
+
+
+def score_head(pooled, lin):
+    """lin(pooled) for the regressor nn.Linear(hidden, 1); any other shape / device / dtype goes to the module itself."""
+    if (lin.out_features == 1 and pooled.is_cuda and pooled.dim() == 2 and pooled.dtype == torch.float32
+            and lin.weight.dtype == torch.float32 and pooled.shape[0] >= 1):
+        return ScoreHead.apply(pooled, lin.weight, lin.bias)
+    return lin(pooled)
+
+
 # ------------------------------------------------------------------------------------------- regression loss
 class RegressionLoss(torch.autograd.Function):
     """mean |score - y| (kind 0, train_ZINC.py:42) or mean (score - y)^2 (kind 1, train_qm9.py:96) with its gradient

@@ -743,6 +743,36 @@ def test_jk_projection_native_vs_torch(N, H, S, O):
     assert torch.equal(wd2.grad, wd3.grad)
 
 
+@pytest.mark.parametrize("G,D,bias", [(2048, 104, True), (1, 104, True), (77, 120, False), (513, 17, True), (64, 300, True)])
+def test_score_head_native_vs_torch(G, D, bias):
+    """The regressor nn.Linear(hidden, 1) on pooled graph rows (models/GraphRegression.py:17,46-51) on kpgnn_score_head_fwd / _bwd
+    against the framework's op on the CPU: scores, d pooled, dW, db; a second call gives the same bits."""
+    from kp_gnn_amd.ops_dense import score_head
+    dev = _dev()
+    g = torch.Generator().manual_seed(G + D)
+    lin = torch.nn.Linear(D, 1, bias=bias)
+    pooled = torch.randn(G, D, generator=g) * 3
+    gy = torch.randn(G, 1, generator=g)
+    pr = pooled.clone().requires_grad_(True)
+    (lin(pr) * gy).sum().backward()
+    import copy
+    lind = copy.deepcopy(lin).to(dev)
+    lind.zero_grad()
+    pd = pooled.clone().to(dev).requires_grad_(True)
+    out = score_head(pd, lind)
+    assert out.shape == (G, 1)
+    (out * gy.to(dev)).sum().backward()
+    _close(out, lin(pooled).detach(), "score", rtol=2e-5, atol=2e-5)
+    _close(pd.grad, pr.grad, "dpooled", rtol=1e-6, atol=1e-7)
+    _close(lind.weight.grad, lin.weight.grad, "dW", rtol=2e-4, atol=2e-4)
+    if bias:
+        _close(lind.bias.grad, lin.bias.grad, "db", rtol=2e-4, atol=2e-5)
+    w1 = lind.weight.grad.clone()
+    lind.zero_grad()
+    (score_head(pd.detach(), lind) * gy.to(dev)).sum().backward()
+    assert torch.equal(w1, lind.weight.grad)
+
+
 def test_linear_wgrad_relu_mask_on_load():
     """kpgnn_linear_wgrad with dy_mask: dW = (dy * [mask > 0])^T x without the masked copy."""
     import ctypes
