@@ -208,6 +208,12 @@ int kpgnn_reduce_jobs(const kpgnn_reduce_job* jobs, int32_t count, kpgnn_stream_
  * other configurations answer KPGNN_EINVAL.  (BASELINE configs[1] names bf16; tolerance 2e-2 relative) */
 enum { KPGNN_STORE_F32 = 0, KPGNN_STORE_BF16 = 1 };
 
+/* Arithmetic of the dense fp32 products that offer a choice.  AUTO: the bf16-split product where the kernel has one for the
+ * shape - every fp32 operand is the exact sum of three bf16 pieces, the six leading piece products run on the bf16 matrix
+ * cores with fp32 accumulation (dropped terms < 2^-24 of a product: the error of fp32 accumulation itself) - else F32.
+ * F32: v_mfma_f32_32x32x2_f32 always. */
+enum { KPGNN_MATH_AUTO = 0, KPGNN_MATH_F32 = 1 };
+
 enum {
     KPGNN_MODE_GIN = 0,     /* out = S + P + (1+eps)*x                  KPGIN.py:100-105, gine.py:52-53 */
     KPGNN_MODE_GINPLUS = 1, /* out = gelu(S) + P                        KPGINplus.py:74-77,87-88        */
@@ -599,6 +605,7 @@ typedef struct kpgnn_wgrad_desc {
      * rows then serves batches of any size up to it (kpgnn_collate leaves the count in its header): rows >= *n_dyn are
      * neither read nor summed.  NULL: all N rows. */
     const int32_t* n_dyn;
+    int32_t math;               /* KPGNN_MATH_* (bf16-split product: O <= 128, I <= 128, 16-B aligned operands) */
 } kpgnn_wgrad_desc;
 
 size_t kpgnn_wgrad_workspace_bytes(int32_t O, int32_t I);

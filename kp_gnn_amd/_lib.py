@@ -120,14 +120,22 @@ class ReduceJob(ctypes.Structure):
     _fields_ = [("slab", c_vp), ("nslab", c_i32), ("elems", c_i64), ("out", c_vp * 4), ("n_out", c_i64 * 4)]
 
 
+MATH_AUTO, MATH_F32 = 0, 1     # include/kpgnn.h KPGNN_MATH_*
+DENSE_MATH = MATH_AUTO          # what new dense descriptors ask for (ops_dense.set_dense_math)
+
+
 class WgradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("dy", c_vp), ("dy_stride", c_i64), ("x", c_vp), ("x_stride", c_i64),
         ("dw", c_vp), ("db", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
         ("x_mean", c_vp), ("x_invstd", c_vp), ("x_gamma", c_vp), ("x_beta", c_vp), ("x_relu", c_i32),
-        ("defer", c_vp), ("dy_mask", c_vp), ("n_dyn", c_vp),
+        ("defer", c_vp), ("dy_mask", c_vp), ("n_dyn", c_vp), ("math", c_i32),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.math = DENSE_MATH
 
 
 class LinearBnDesc(ctypes.Structure):

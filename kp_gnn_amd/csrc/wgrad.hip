@@ -10,6 +10,7 @@
 // leaves behind: 512 single-group blocks wrote (and the reduce launch re-read) 44.7 MB per pair of 104 x 104 problems,
 // against 80 MB of operands; two groups per block halve it.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kpgnn_common.h"
 
@@ -370,6 +371,259 @@ wgrad2_kernel(const Wg2Args A) {
     if (q.bias_off >= 0 && kk == 0 && o_ok) out[q.bias_off + o] = bsum;
 }
 
+// ------------------------------------------------------------------------------------------------ bf16-split variant
+// The fp32 matrix instruction above runs at 1/16 of the bf16 rate and the chip holds ~1.6 GHz under it: the kernel sits at
+// 65-85 TFLOP/s, twice its operand time from HBM.  An fp32 value is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 significant
+// bits, split by truncation: h = top 16 bits of v, m = top 16 bits of v - h, l = v - h - m), so
+//     a b = ah bh + (ah bm + am bh) + (am bm + ah bl + al bh) + [three terms below 2^-24 |a b|: dropped]:
+// six exact bf16 products per k on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - 6/16 of the matrix time of the fp32
+// instruction for the rounding error of fp32 accumulation itself (smallest terms first within a k step).  The bf16 instruction wants 8 consecutive k (= rows) of one column per lane, so the
+// chunk is staged COLUMN-major: a thread fetches 8 rows x 4 columns (8 float4 requests, a chunk ahead), splits them and
+// writes 4 x 3 packed 16-byte items; 80-byte column pitch = conflict-free 16-byte reads.
+typedef __attribute__((ext_vector_type(8))) __bf16 w3_bf16x8;
+constexpr int kW3Pitch = 40;      // bf16 per staged column: 32 rows + 8 of padding
+
+__device__ __forceinline__ void w3_split(const float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));       // (<= 8 significant bits left: its top half is all of it)
+}
+// the top halves of two words side by side: low half <- a, high half <- b
+__device__ __forceinline__ uint32_t w3_pack(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// Roles: waves 0-3 only multiply (one 32-row output strip each), waves 4-7 only stage (4-5 dy, 6-7 x) into the OTHER of two
+// LDS buffers, their global requests two chunks ahead in two register sets; one barrier per chunk.
+// Measured (s_memtime per phase, [47450,104] operands): a chunk costs ~3750 cycles - the multiplying wave 2200 (48 matrix
+// instructions = 1536, the rest exposed LDS read latency), the staging wave on the same SIMD 400-1300 to have its rows, 1050
+// (alone) to 2300 (next to a multiplying wave) for ~160 vector instructions and 12 stores, 400-900 to request the next rows:
+// vector and matrix work of two waves on one SIMD add up rather than overlap.  29.6 us per pair of problems against 47.4 for
+// the fp32 kernel, 120 against 191 for nine problems (the jumping-knowledge projection); the operands' HBM time is 16 / 40 us.
+constexpr int kW3Blocks = 256;    // one 8-wave block per CU
+
+typedef __attribute__((ext_vector_type(2))) float w3_f2;
+typedef __attribute__((ext_vector_type(2))) uint32_t w3_u2;
+
+// three-way split of two values at once (packed subtracts): word pairs whose top halves are the bf16 pieces
+__device__ __forceinline__ void w3_split2(const w3_f2 v, w3_u2& h, w3_u2& m, w3_u2& l) {
+    h = __builtin_bit_cast(w3_u2, v) & 0xffff0000u;
+    const w3_f2 r1 = v - __builtin_bit_cast(w3_f2, h);
+    m = __builtin_bit_cast(w3_u2, r1) & 0xffff0000u;
+    l = __builtin_bit_cast(w3_u2, r1 - __builtin_bit_cast(w3_f2, m));
+}
+
+template <int TI, bool MASK>
+__global__ void __launch_bounds__(512, 1)
+wgrad3_kernel(const Wg2Args A) {
+    extern __shared__ __attribute__((aligned(16))) float w2[];
+    constexpr int R = kW2Rows, P = kW3Pitch;
+    const int O = A.O, I = A.I;
+    const int bufsz = 3 * (O + I) * P;                     // bf16 items per buffer: [3][O][P] pieces of dy, then [3][I][P] of x
+    __bf16* pl = reinterpret_cast<__bf16*>(w2);
+    float* coef = reinterpret_cast<float*>(pl + 2 * bufsz);   // [4][I] x transform; afterwards [4][O] bias partials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the role tests below become scalar branches)
+    const int kg = lane >> 5, c = lane & 31;
+    const int nprob = A.nprob;
+    const int pi = (int)(blockIdx.x % nprob), slice = (int)(blockIdx.x / nprob), nslices = (int)(gridDim.x / nprob);
+    Wg2Prob q = A.q[0];
+#pragma unroll
+    for (int i = 1; i < kW2MaxProb; ++i)
+        if (pi == i) q = A.q[i];
+    const int64_t N = A.n_dyn ? (int64_t)min((int64_t)*A.n_dyn, A.N) : A.N;
+    const bool tr = q.xm != nullptr;
+    if (tr)
+        for (int i = tid; i < I; i += 512) { coef[i] = q.xm[i]; coef[I + i] = q.xi[i]; coef[2 * I + i] = q.xg[i]; coef[3 * I + i] = q.xb[i]; }
+    const int64_t chunks = (N + R - 1) / R;
+    const int64_t mine = slice < chunks ? (chunks - slice + nslices - 1) / nslices : 0;     // chunks slice, slice + nslices, ...
+    const bool producer = wave >= 4;
+    // ---- staging task of a producer thread, fixed for the launch: (row group of 8, 4 columns) of dy (waves 4-5) or x (6-7)
+    const bool is_x = wave >= 6;
+    const int ncg = (is_x ? I : O) >> 2;
+    const int task = tid & 127;
+    const bool owner = producer && task < 4 * ncg;
+    // (row group fastest: the 8 contiguous lanes a 16-byte LDS store is serviced in then hit 8 distinct bank quads - column
+    //  fastest was a 4-way conflict on every store - and a wave's request still covers 256-byte pieces of 4 rows)
+    const int g = owner ? task & 3 : 0, cg = owner ? task >> 2 : 0;
+    const float* src = is_x ? q.x : q.dy;
+    const int64_t sstride = is_x ? q.xs : q.dys;
+    const uint32_t sbytes = (uint32_t)sstride * 4u;           // (row pitch in bytes < 2^24: checked by the host)
+    const bool xform = tr && is_x;
+    const int64_t last = N - 1;
+    w3_f2 bs01 = {0.f, 0.f}, bs23 = {0.f, 0.f};            // dy tasks: column sums of this thread's rows (the bias gradient)
+    // The staging loop, instantiated per role (M: this wave applies the ReLU mask to what it stages, i.e. it stages dy and there is one).
+    auto produce = [&](auto mask_c) {
+        constexpr bool M = decltype(mask_c)::value;
+        float4 pv0[8], pm0[8], pv1[8], pm1[8];
+        // Requests are unconditional in every respect - clamped rows, clamped chunk index, no branch on the role or the mask: the
+        // compiler then knows how many requests are in flight at each use and waits for exactly the oldest (one `if` around an
+        // issue and it must assume the younger set was never requested: vmcnt(7) at the first use, i.e. a wait for both sets).
+        auto issue = [&](int64_t k, float4 (&pv)[8], float4 (&pm)[8]) {
+            const int64_t c0 = (slice + min(k, mine - 1) * nslices) * R;          // (scalar)
+            const float* cp = src + c0 * sstride;                                  // (scalar) the chunk's first row
+            const float* mp = M ? q.mask + c0 * sstride : nullptr;
+            const int lim = (int)min((int64_t)R, N - c0) - 1;                     // (scalar) last valid row of the chunk
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // (rows beyond N: the chunk's last valid row.  Unsigned 32-bit BYTE offset from a scalar base: one min, one 24-bit mad)
+                const uint32_t off = __umul24((uint32_t)min(8 * g + j, lim), sbytes) + 16u * (uint32_t)cg;
+                pv[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cp) + off);
+                if (M) pm[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mp) + off);
+            }
+        };
+        auto commit = [&](int64_t k, float4 (&pv)[8], float4 (&pm)[8]) {       // (k >= mine: the clamped chunk again, into a buffer nobody reads)
+            const int64_t c0 = (slice + min(k, mine - 1) * nslices) * R;
+            if (M) {
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pv[j].x = pm[j].x > 0.f ? pv[j].x : 0.f; pv[j].y = pm[j].y > 0.f ? pv[j].y : 0.f;
+                    pv[j].z = pm[j].z > 0.f ? pv[j].z : 0.f; pv[j].w = pm[j].w > 0.f ? pv[j].w : 0.f;
+                }
+            }
+            if (xform) {
+                const float4 m4 = *reinterpret_cast<const float4*>(coef + 4 * cg), s4 = *reinterpret_cast<const float4*>(coef + I + 4 * cg);
+                const float4 g4 = *reinterpret_cast<const float4*>(coef + 2 * I + 4 * cg), b4 = *reinterpret_cast<const float4*>(coef + 3 * I + 4 * cg);
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float4 v = pv[j];
+                    v.x = fmaf((v.x - m4.x) * s4.x, g4.x, b4.x); v.y = fmaf((v.y - m4.y) * s4.y, g4.y, b4.y);
+                    v.z = fmaf((v.z - m4.z) * s4.z, g4.z, b4.z); v.w = fmaf((v.w - m4.w) * s4.w, g4.w, b4.w);
+                    if (q.xrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    pv[j] = v;
+                }
+            }
+            if (c0 + R > N) {                                                      // (uniform: only a launch's last chunk) rows beyond N stay zero
+    #pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + 8 * g + j >= N) pv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!is_x && k < mine) {
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) { bs01 += w3_f2{pv[j].x, pv[j].y}; bs23 += w3_f2{pv[j].z, pv[j].w}; }
+            }
+            if (owner) {
+                __bf16* base = pl + (k & 1) * bufsz + (is_x ? 3 * O * P : 0) + 8 * g;
+                const int cols = is_x ? I : O;
+    #pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {                                   // two columns at a time: 48 live pieces, not 96
+                    w3_u2 h[8], m[8], l[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        w3_split2(e2 == 0 ? w3_f2{pv[j].x, pv[j].y} : w3_f2{pv[j].z, pv[j].w}, h[j], m[j], l[j]);
+                    __bf16* col = base + (4 * cg + 2 * e2) * P;
+                    *reinterpret_cast<uint4*>(col) = make_uint4(w3_pack(h[0].x, h[1].x), w3_pack(h[2].x, h[3].x), w3_pack(h[4].x, h[5].x), w3_pack(h[6].x, h[7].x));
+                    *reinterpret_cast<uint4*>(col + P) = make_uint4(w3_pack(h[0].y, h[1].y), w3_pack(h[2].y, h[3].y), w3_pack(h[4].y, h[5].y), w3_pack(h[6].y, h[7].y));
+                    *reinterpret_cast<uint4*>(col + cols * P) = make_uint4(w3_pack(m[0].x, m[1].x), w3_pack(m[2].x, m[3].x), w3_pack(m[4].x, m[5].x), w3_pack(m[6].x, m[7].x));
+                    *reinterpret_cast<uint4*>(col + cols * P + P) = make_uint4(w3_pack(m[0].y, m[1].y), w3_pack(m[2].y, m[3].y), w3_pack(m[4].y, m[5].y), w3_pack(m[6].y, m[7].y));
+                    *reinterpret_cast<uint4*>(col + 2 * cols * P) = make_uint4(w3_pack(l[0].x, l[1].x), w3_pack(l[2].x, l[3].x), w3_pack(l[4].x, l[5].x), w3_pack(l[6].x, l[7].x));
+                    *reinterpret_cast<uint4*>(col + 2 * cols * P + P) = make_uint4(w3_pack(l[0].y, l[1].y), w3_pack(l[2].y, l[3].y), w3_pack(l[4].y, l[5].y), w3_pack(l[6].y, l[7].y));
+                }
+            }
+        };
+        __builtin_amdgcn_s_setprio(2);     // (the staging waves' vector work first: measured 3750 against 4100 cycles per chunk)
+        if (mine > 0) {
+            issue(0, pv0, pm0);
+            issue(1, pv1, pm1);
+            commit(0, pv0, pm0);
+            issue(2, pv0, pm0);
+        }
+        __syncthreads();
+        for (int64_t k = 0; k < mine; k += 2) {
+            commit(k + 1, pv1, pm1);
+            issue(k + 3, pv1, pm1);
+            __syncthreads();
+            commit(k + 2, pv0, pm0);
+            issue(k + 4, pv0, pm0);
+            __syncthreads();
+        }
+    };
+    f32x16 acc[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    const int o = wave * 32 + c;
+    const bool strip = !producer && wave * 32 < O;          // (wave-uniform: O <= 96 leaves the last strip without work)
+    // (padded lanes read the last valid column: what they accumulate lands in rows / columns that are never stored)
+    const int aoff = min(o, O - 1) * P + 8 * kg;
+    int boff[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) boff[t] = 3 * O * P + min(t * 32 + c, I - 1) * P + 8 * kg;
+    auto ld8 = [&](const __bf16* ptr) { return __builtin_bit_cast(w3_bf16x8, *reinterpret_cast<const uint4*>(ptr)); };
+    auto multiply = [&](int64_t k) {
+        const __bf16* bf = pl + (k & 1) * bufsz;
+#pragma unroll
+        for (int ks = 0; ks < R / 16; ++ks) {
+            const w3_bf16x8 ah = ld8(bf + aoff + 16 * ks), am = ld8(bf + aoff + O * P + 16 * ks), al = ld8(bf + aoff + 2 * O * P + 16 * ks);
+            w3_bf16x8 bh[TI], bm[TI], bl[TI];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                bh[t] = ld8(bf + boff[t] + 16 * ks); bm[t] = ld8(bf + boff[t] + I * P + 16 * ks); bl[t] = ld8(bf + boff[t] + 2 * I * P + 16 * ks);
+            }
+            // smallest terms first; consecutive instructions feed different accumulators
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+        }
+    };
+    if (tr) __syncthreads();
+    // Chunk k of this block is staged into buffer k & 1 during step k - 1 and multiplied during step k; the requests for k + 2
+    // leave when k's registers are free (two named register sets, loop unrolled by two).  The two roles run their OWN loops with
+    // the same number of barriers (1 + 2 ceil(mine / 2)): in one shared loop the accumulators stay live across the staging code and the
+    // staging registers across the matrix code (140 spills).
+    float* out = A.slab + (int64_t)slice * A.slab_row;
+    if (producer) {
+        if (MASK && !is_x) produce(std::true_type{});
+        else produce(std::false_type{});
+    } else {
+        __syncthreads();
+        for (int64_t k = 0; k < mine; k += 2) {
+            if (strip) multiply(k);
+
+            __syncthreads();
+
+            if (strip && k + 1 < mine) multiply(k + 1);
+
+            __syncthreads();
+        }
+        if (strip) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int i = t * 32 + c;
+                for (int v = 0; v < 16; ++v) {
+                    const int orow = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * kg;
+                    if (orow < O && i < I) out[q.out_off + (int64_t)orow * A.ldw + i] = acc[t][v];
+                }
+            }
+        }
+    }
+    if (q.bias_off >= 0) {                            // (uniform) the four row groups' column sums, in row-group order
+        if (owner && !is_x) *reinterpret_cast<float4*>(coef + g * O + 4 * cg) = make_float4(bs01.x, bs01.y, bs23.x, bs23.y);
+        __syncthreads();
+        if (tid < O) out[q.bias_off + tid] = (coef[tid] + coef[O + tid]) + (coef[2 * O + tid] + coef[3 * O + tid]);
+    }
+}
+
+bool wgrad3_ok(const Wg2Args& A) {
+    for (int i = 1; i < A.nprob; ++i)
+        if ((A.q[i].mask != nullptr) != (A.q[0].mask != nullptr)) return false;      // (one instantiation per launch)
+    for (int i = 0; i < A.nprob; ++i)
+        if (A.q[i].dys >= (1 << 22) || A.q[i].xs >= (1 << 22)) return false;                   // (24-bit byte pitch)
+    return A.O <= 128 && A.I <= 128;
+}
+size_t wgrad3_lds(const Wg2Args& A) {
+    const int m = A.O > A.I ? A.O : A.I;
+    return (size_t)2 * 2 * 3 * (A.O + A.I) * kW3Pitch + sizeof(float) * 4 * (size_t)m;
+}
+
 bool wgrad2_ok(const kpgnn_wgrad_desc* d, const float* x) {
     auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     return d->O % 4 == 0 && d->I % 4 == 0 && d->O <= 128 && d->I <= 256 && d->dy_stride % 4 == 0 && d->x_stride % 4 == 0 &&
@@ -384,17 +638,38 @@ Wg2Prob wgrad2_prob(const kpgnn_wgrad_desc* d, const float* x, int64_t out_off, 
 }
 
 // slices (= slab rows) per problem: the problems share the chip's 2 x 256 block slots; >= 1 chunk of rows per slice
-int wgrad2_slices(int64_t N, int nprob) {
+int wgrad2_slices(int64_t N, int nprob, int blocks) {
     const int64_t chunks = (N + kW2Rows - 1) / kW2Rows;
-    int64_t s = kWgradBlocks / nprob;
+    int64_t s = blocks / nprob;
     if (s > chunks) s = chunks;
     return (int)(s < 1 ? 1 : s);
 }
 
-int wgrad2_launch(Wg2Args& A, int nslices, hipStream_t s) {
+// Launches the problems of A; *nslices = slab rows written (the caller's reduction covers exactly those).
+int wgrad2_launch(Wg2Args& A, int math, int* nslices, hipStream_t s) {
     const int ti = (A.I + 31) / 32;
+    if (math != KPGNN_MATH_F32 && wgrad3_ok(A)) {
+        *nslices = wgrad2_slices(A.N, A.nprob, kW3Blocks);
+        dim3 gr3((unsigned)(*nslices * A.nprob)), blk3(512);
+        const size_t lds3 = wgrad3_lds(A);
+        const bool mask = A.q[0].mask != nullptr;      // (the problems of a launch share dy and its mask, or have none)
+#define KP_W3(T) do { if (mask) { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)wgrad3_kernel<T, true>, lds3)); \
+                                  hipLaunchKernelGGL((wgrad3_kernel<T, true>), gr3, blk3, lds3, s, A); } \
+                      else { KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)wgrad3_kernel<T, false>, lds3)); \
+                             hipLaunchKernelGGL((wgrad3_kernel<T, false>), gr3, blk3, lds3, s, A); } } while (0)
+        switch (ti) {
+            case 1: KP_W3(1); break;
+            case 2: KP_W3(2); break;
+            case 3: KP_W3(3); break;
+            default: KP_W3(4); break;
+        }
+#undef KP_W3
+        KPGNN_LAUNCH_CHECK("wgrad3_kernel");
+        return KPGNN_OK;
+    }
+    *nslices = wgrad2_slices(A.N, A.nprob, kWgradBlocks);
+    dim3 gr((unsigned)(*nslices * A.nprob)), blk(256);
     const size_t lds = sizeof(float) * ((size_t)kW2Rows * (A.O + A.I) + 4 * (size_t)A.I);
-    dim3 gr((unsigned)(nslices * A.nprob)), blk(256);
 #define KP_W2(T) hipLaunchKernelGGL((wgrad2_kernel<T>), gr, blk, lds, s, A)
     switch (ti) {
         case 1: KP_W2(1); break;
@@ -433,8 +708,7 @@ extern "C" int kpgnn_linear_wgrad(const kpgnn_wgrad_desc* d, kpgnn_stream_t stre
         Wg2Args A;
         A.N = d->N; A.n_dyn = d->n_dyn; A.O = d->O; A.I = d->I; A.nprob = 1; A.ldw = d->I; A.slab = slab; A.slab_row = nw + d->O;
         for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(d, d->x, 0, nw);
-        grid = wgrad2_slices(d->N, 1);
-        rc = wgrad2_launch(A, grid, s);
+        rc = wgrad2_launch(A, d->math, &grid, s);
     } else {
         KPGNN_REQUIRE(!d->dy_mask && !d->n_dyn, "linear_wgrad: dy_mask / n_dyn need 16-B aligned operands with O %% 4 == I %% 4 == 0, O <= 128");
         WgPair pp;
@@ -471,8 +745,7 @@ extern "C" int kpgnn_linear_wgrad_pair(const kpgnn_wgrad_desc* a, const kpgnn_wg
         A.N = a->N; A.n_dyn = a->n_dyn; A.O = a->O; A.I = a->I; A.nprob = 2; A.ldw = a->I; A.slab = slab; A.slab_row = 2 * one;
         for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(a, a->x, 0, nw);
         A.q[1] = wgrad2_prob(b, b->x, one, one + nw);
-        grid = wgrad2_slices(a->N, 2);
-        rc = wgrad2_launch(A, grid, s);
+        rc = wgrad2_launch(A, a->math, &grid, s);
     } else {
         KPGNN_REQUIRE(!a->dy_mask && !b->dy_mask && !a->n_dyn, "linear_wgrad_pair: dy_mask / n_dyn need 16-B aligned operands");
         WgPair pp;
@@ -513,9 +786,9 @@ extern "C" int kpgnn_linear_wgrad_group(const kpgnn_wgrad_desc* d, const float* 
     A.N = d->N; A.n_dyn = d->n_dyn; A.O = d->O; A.I = d->I; A.nprob = group; A.ldw = (int64_t)d->I * group;
     A.slab = (float*)d->workspace; A.slab_row = nw + d->O;
     for (int i = 0; i < kW2MaxProb; ++i) A.q[i] = wgrad2_prob(d, x_group[i < group ? i : 0], (int64_t)(i < group ? i : 0) * d->I, i == 0 ? nw : -1);
-    const int grid = wgrad2_slices(d->N, group);
+    int grid = 0;
     hipStream_t s = (hipStream_t)stream;
-    rc = wgrad2_launch(A, grid, s);
+    rc = wgrad2_launch(A, d->math, &grid, s);
     if (rc != KPGNN_OK) return rc;
     float* db = d->db ? d->db : A.slab + (size_t)grid * A.slab_row;     // sink behind the slab rows
     if (d->defer) {

@@ -139,6 +139,12 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dgb[0], dgb[1], gres, None, None, None, None, None, None, None
 
 
+def set_dense_math(mode):
+    """"auto": the bf16-split products on the bf16 matrix cores where a kernel has them (include/kpgnn.h KPGNN_MATH_AUTO);
+    "f32": the fp32 matrix instruction everywhere.  Applies to descriptors created afterwards."""
+    _lib.DENSE_MATH = {"auto": _lib.MATH_AUTO, "f32": _lib.MATH_F32}[mode]
+
+
 _LIN_WIDTHS = (32, 64, 96, 104, 128)   # lin_fused.h: fully unrolled k-loops
 
 # kpgnn_linear_fwd: y = x W^T + b and dx = dy W for tall-skinny x on the fp32 matrix cores.  Measured 21.8 us per

@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kp_gnn_amd import _lib
 
 lib = _lib.load()
+_lib.DENSE_MATH = {"auto": _lib.MATH_AUTO, "f32": _lib.MATH_F32}.get(os.environ.get("UB_MATH", "auto"), None)
+if _lib.DENSE_MATH is None:
+    _lib.DENSE_MATH = int(os.environ["UB_MATH"])   # UB_MATH=f32: fp32 matrix instruction
+print("dense math:", os.environ.get("UB_MATH", "auto"))
 dev = torch.device("cuda:0")
 N, H, S = int(os.environ.get("UB_N", 47450)), 104, 9
 st = torch.cuda.current_stream().cuda_stream
@@ -56,6 +60,10 @@ job = _lib.ReduceJob()
 qa.defer = ctypes.cast(ctypes.pointer(job), ctypes.c_void_p)
 timeit("wgrad pair (reduce deferred)", lambda: _lib.check(lib.kpgnn_linear_wgrad_pair(ctypes.byref(qa), ctypes.byref(qb), st), "wgp"), 4.0 * N * H * H)
 qa.defer = None
+
+ref = dy.double().t() @ x.double()
+err = ((dw[0].double() - ref).abs().max() / ref.abs().max()).item()
+print(f"wgrad dW max error / max |dW| against float64: {err:.3e};  db error {((db[0].double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max()).item():.3e}")
 
 # JK: grouped forward, blocked dX, grouped wgrad
 states = [torch.randn(N, H, device=dev) for _ in range(S)]
