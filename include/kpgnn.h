@@ -642,9 +642,15 @@ typedef struct kpgnn_linear_desc {
     /* Optional (O > 128 only) ReLU mask of x on load (device [N,I], rows x_stride apart): x' = x where x_mask > 0, else 0. */
     const float* x_mask;
     const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N), as in kpgnn_wgrad_desc */
+    int32_t math;                         /* KPGNN_MATH_* (bf16-split product: blocked output with y_block_cols <= 128, no bias, N >= 4096) */
+    /* Optional device scratch for the bf16-split product (the split copy of w in matrix-fragment order), 16-B aligned,
+     * >= kpgnn_linear_split_workspace_bytes(y_block_cols, I, O / y_block_cols).  NULL: the fp32 kernels. */
+    void* workspace; size_t workspace_bytes;
 } kpgnn_linear_desc;
 
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
+/* Bytes of the split copy of `group` weight blocks of [O, I] (O, I <= 128) for the bf16-split kernels; 0 for shapes they do not take. */
+size_t kpgnn_linear_split_workspace_bytes(int32_t O, int32_t I, int32_t group);
 
 /* y = act(sum_l x_l W[:, l*I:(l+1)*I]^T + b): nn.Linear over the concatenation of `group` (<= 16) states x_l [N,I] that live
  * in SEPARATE tensors - the bodies' jumping-knowledge projection `output_proj(torch.cat(h_list, dim=-1))`
@@ -658,6 +664,8 @@ typedef struct kpgnn_linear_group_desc {
     const float* w; const float* bias; float* y;
     int32_t relu;
     const int32_t* n_dyn;                 /* optional live-row count (device int32[1], <= N) */
+    int32_t math;                         /* KPGNN_MATH_* (bf16-split product: N >= 4096) */
+    void* workspace; size_t workspace_bytes;  /* optional, >= kpgnn_linear_split_workspace_bytes(O, I, group); NULL: the fp32 kernel */
 } kpgnn_linear_group_desc;
 int kpgnn_linear_group_fwd(const kpgnn_linear_group_desc* d, kpgnn_stream_t stream);
 

@@ -169,14 +169,24 @@ class LinearDesc(ctypes.Structure):
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
         ("x", c_vp), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("y_stride", c_i64),
         ("w_transposed", c_i32), ("y_block_cols", c_i32), ("y_block_stride", c_i64), ("x_mask", c_vp), ("n_dyn", c_vp),
+        ("math", c_i32), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.math = DENSE_MATH
 
 
 class LinearGroupDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32), ("group", c_i32),
         ("x", c_vp * 16), ("x_stride", c_i64), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("relu", c_i32), ("n_dyn", c_vp),
+        ("math", c_i32), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.math = DENSE_MATH
 
 
 class HopMlpDesc(ctypes.Structure):
@@ -293,6 +303,7 @@ SIGNATURES = {
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
+    "kpgnn_linear_split_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
     "kpgnn_linear_group_fwd": (ctypes.c_int, [ctypes.POINTER(LinearGroupDesc), c_vp]),
     "kpgnn_geo_theta_fwd": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_geo_theta_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),

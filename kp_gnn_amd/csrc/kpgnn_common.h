@@ -61,6 +61,11 @@ const DeviceFacts& device_facts();
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a slow host call: do it once per kernel, raising only.
 hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
+// linear_bf3.hip: the bf16-split kernels behind kpgnn_linear_group_fwd / kpgnn_linear_fwd (blocked output); *handled = false
+// when the shape (or d->math) leaves the launch to the fp32 kernels
+size_t linear3_workspace_bytes(int O, int I, int group);
+int linear3_group_fwd(const kpgnn_linear_group_desc* d, hipStream_t s, bool* handled);
+int linear3_blocked(const kpgnn_linear_desc* d, hipStream_t s, bool* handled);
 
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).

@@ -148,6 +148,8 @@ linear_group_kernel(const LgParams p) {
 
 using namespace kpgnn;
 
+extern "C" size_t kpgnn_linear_split_workspace_bytes(int32_t O, int32_t I, int32_t group) { return linear3_workspace_bytes(O, I, group); }
+
 extern "C" int kpgnn_linear_group_fwd(const kpgnn_linear_group_desc* d, kpgnn_stream_t stream) {
     KPGNN_REQUIRE(d != nullptr, "linear_group_fwd: NULL descriptor");
     KPGNN_REQUIRE(d->N >= 1 && d->O >= 1 && d->I >= 1 && d->group >= 1 && d->group <= 16, "linear_group_fwd: bad N=%lld O=%d I=%d group=%d",
@@ -163,6 +165,11 @@ extern "C" int kpgnn_linear_group_fwd(const kpgnn_linear_group_desc* d, kpgnn_st
     for (int l = 0; l < 16; ++l) {
         p.xs[l] = d->x[l < d->group ? l : 0];
         if (l < d->group && (!p.xs[l] || !al(p.xs[l]))) return fail(KPGNN_ELIMIT, "linear_group_fwd: state %d is NULL or not 16-B aligned", l);
+    }
+    {
+        bool handled = false;
+        const int rc = linear3_group_fwd(d, (hipStream_t)stream, &handled);       // the bf16-split kernel, where it applies
+        if (handled || rc != KPGNN_OK) return rc;
     }
     p.xstride = d->x_stride; p.w = d->w; p.bias = d->bias; p.y = d->y;
     p.pitch = d->I + ((4 - d->I % 8) + 8) % 8;          // pitch = 4 (mod 8) floats: 16-B aligned rows, conflict-free operand reads

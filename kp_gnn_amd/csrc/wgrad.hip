@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "bf3.h"
 #include "kpgnn_common.h"
 
 namespace kpgnn {
@@ -380,17 +381,7 @@ wgrad2_kernel(const Wg2Args A) {
 // instruction for the rounding error of fp32 accumulation itself (smallest terms first within a k step).  The bf16 instruction wants 8 consecutive k (= rows) of one column per lane, so the
 // chunk is staged COLUMN-major: a thread fetches 8 rows x 4 columns (8 float4 requests, a chunk ahead), splits them and
 // writes 4 x 3 packed 16-byte items; 80-byte column pitch = conflict-free 16-byte reads.
-typedef __attribute__((ext_vector_type(8))) __bf16 w3_bf16x8;
 constexpr int kW3Pitch = 40;      // bf16 per staged column: 32 rows + 8 of padding
-
-__device__ __forceinline__ void w3_split(const float v, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = __float_as_uint(v) & 0xffff0000u;
-    const float r1 = v - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));       // (<= 8 significant bits left: its top half is all of it)
-}
-// the top halves of two words side by side: low half <- a, high half <- b
-__device__ __forceinline__ uint32_t w3_pack(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // Roles: waves 0-3 only multiply (one 32-row output strip each), waves 4-7 only stage (4-5 dy, 6-7 x) into the OTHER of two
 // LDS buffers, their global requests two chunks ahead in two register sets; one barrier per chunk.
@@ -401,15 +392,15 @@ __device__ __forceinline__ uint32_t w3_pack(uint32_t a, uint32_t b) { return __b
 // the fp32 kernel, 120 against 191 for nine problems (the jumping-knowledge projection); the operands' HBM time is 16 / 40 us.
 constexpr int kW3Blocks = 256;    // one 8-wave block per CU
 
-typedef __attribute__((ext_vector_type(2))) float w3_f2;
-typedef __attribute__((ext_vector_type(2))) uint32_t w3_u2;
+typedef __attribute__((ext_vector_type(2))) float bf3_f2;
+typedef __attribute__((ext_vector_type(2))) uint32_t bf3_u2;
 
 // three-way split of two values at once (packed subtracts): word pairs whose top halves are the bf16 pieces
-__device__ __forceinline__ void w3_split2(const w3_f2 v, w3_u2& h, w3_u2& m, w3_u2& l) {
-    h = __builtin_bit_cast(w3_u2, v) & 0xffff0000u;
-    const w3_f2 r1 = v - __builtin_bit_cast(w3_f2, h);
-    m = __builtin_bit_cast(w3_u2, r1) & 0xffff0000u;
-    l = __builtin_bit_cast(w3_u2, r1 - __builtin_bit_cast(w3_f2, m));
+__device__ __forceinline__ void bf3_split2(const bf3_f2 v, bf3_u2& h, bf3_u2& m, bf3_u2& l) {
+    h = __builtin_bit_cast(bf3_u2, v) & 0xffff0000u;
+    const bf3_f2 r1 = v - __builtin_bit_cast(bf3_f2, h);
+    m = __builtin_bit_cast(bf3_u2, r1) & 0xffff0000u;
+    l = __builtin_bit_cast(bf3_u2, r1 - __builtin_bit_cast(bf3_f2, m));
 }
 
 template <int TI, bool MASK>
@@ -450,7 +441,7 @@ wgrad3_kernel(const Wg2Args A) {
     const uint32_t sbytes = (uint32_t)sstride * 4u;           // (row pitch in bytes < 2^24: checked by the host)
     const bool xform = tr && is_x;
     const int64_t last = N - 1;
-    w3_f2 bs01 = {0.f, 0.f}, bs23 = {0.f, 0.f};            // dy tasks: column sums of this thread's rows (the bias gradient)
+    bf3_f2 bs01 = {0.f, 0.f}, bs23 = {0.f, 0.f};            // dy tasks: column sums of this thread's rows (the bias gradient)
     // The staging loop, instantiated per role (M: this wave applies the ReLU mask to what it stages, i.e. it stages dy and there is one).
     auto produce = [&](auto mask_c) {
         constexpr bool M = decltype(mask_c)::value;
@@ -499,24 +490,24 @@ wgrad3_kernel(const Wg2Args A) {
             }
             if (!is_x && k < mine) {
     #pragma unroll
-                for (int j = 0; j < 8; ++j) { bs01 += w3_f2{pv[j].x, pv[j].y}; bs23 += w3_f2{pv[j].z, pv[j].w}; }
+                for (int j = 0; j < 8; ++j) { bs01 += bf3_f2{pv[j].x, pv[j].y}; bs23 += bf3_f2{pv[j].z, pv[j].w}; }
             }
             if (owner) {
                 __bf16* base = pl + (k & 1) * bufsz + (is_x ? 3 * O * P : 0) + 8 * g;
                 const int cols = is_x ? I : O;
     #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {                                   // two columns at a time: 48 live pieces, not 96
-                    w3_u2 h[8], m[8], l[8];
+                    bf3_u2 h[8], m[8], l[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        w3_split2(e2 == 0 ? w3_f2{pv[j].x, pv[j].y} : w3_f2{pv[j].z, pv[j].w}, h[j], m[j], l[j]);
+                        bf3_split2(e2 == 0 ? bf3_f2{pv[j].x, pv[j].y} : bf3_f2{pv[j].z, pv[j].w}, h[j], m[j], l[j]);
                     __bf16* col = base + (4 * cg + 2 * e2) * P;
-                    *reinterpret_cast<uint4*>(col) = make_uint4(w3_pack(h[0].x, h[1].x), w3_pack(h[2].x, h[3].x), w3_pack(h[4].x, h[5].x), w3_pack(h[6].x, h[7].x));
-                    *reinterpret_cast<uint4*>(col + P) = make_uint4(w3_pack(h[0].y, h[1].y), w3_pack(h[2].y, h[3].y), w3_pack(h[4].y, h[5].y), w3_pack(h[6].y, h[7].y));
-                    *reinterpret_cast<uint4*>(col + cols * P) = make_uint4(w3_pack(m[0].x, m[1].x), w3_pack(m[2].x, m[3].x), w3_pack(m[4].x, m[5].x), w3_pack(m[6].x, m[7].x));
-                    *reinterpret_cast<uint4*>(col + cols * P + P) = make_uint4(w3_pack(m[0].y, m[1].y), w3_pack(m[2].y, m[3].y), w3_pack(m[4].y, m[5].y), w3_pack(m[6].y, m[7].y));
-                    *reinterpret_cast<uint4*>(col + 2 * cols * P) = make_uint4(w3_pack(l[0].x, l[1].x), w3_pack(l[2].x, l[3].x), w3_pack(l[4].x, l[5].x), w3_pack(l[6].x, l[7].x));
-                    *reinterpret_cast<uint4*>(col + 2 * cols * P + P) = make_uint4(w3_pack(l[0].y, l[1].y), w3_pack(l[2].y, l[3].y), w3_pack(l[4].y, l[5].y), w3_pack(l[6].y, l[7].y));
+                    *reinterpret_cast<uint4*>(col) = make_uint4(bf3_pack(h[0].x, h[1].x), bf3_pack(h[2].x, h[3].x), bf3_pack(h[4].x, h[5].x), bf3_pack(h[6].x, h[7].x));
+                    *reinterpret_cast<uint4*>(col + P) = make_uint4(bf3_pack(h[0].y, h[1].y), bf3_pack(h[2].y, h[3].y), bf3_pack(h[4].y, h[5].y), bf3_pack(h[6].y, h[7].y));
+                    *reinterpret_cast<uint4*>(col + cols * P) = make_uint4(bf3_pack(m[0].x, m[1].x), bf3_pack(m[2].x, m[3].x), bf3_pack(m[4].x, m[5].x), bf3_pack(m[6].x, m[7].x));
+                    *reinterpret_cast<uint4*>(col + cols * P + P) = make_uint4(bf3_pack(m[0].y, m[1].y), bf3_pack(m[2].y, m[3].y), bf3_pack(m[4].y, m[5].y), bf3_pack(m[6].y, m[7].y));
+                    *reinterpret_cast<uint4*>(col + 2 * cols * P) = make_uint4(bf3_pack(l[0].x, l[1].x), bf3_pack(l[2].x, l[3].x), bf3_pack(l[4].x, l[5].x), bf3_pack(l[6].x, l[7].x));
+                    *reinterpret_cast<uint4*>(col + 2 * cols * P + P) = make_uint4(bf3_pack(l[0].y, l[1].y), bf3_pack(l[2].y, l[3].y), bf3_pack(l[4].y, l[5].y), bf3_pack(l[6].y, l[7].y));
                 }
             }
         };
@@ -548,13 +539,13 @@ wgrad3_kernel(const Wg2Args A) {
     int boff[TI];
 #pragma unroll
     for (int t = 0; t < TI; ++t) boff[t] = 3 * O * P + min(t * 32 + c, I - 1) * P + 8 * kg;
-    auto ld8 = [&](const __bf16* ptr) { return __builtin_bit_cast(w3_bf16x8, *reinterpret_cast<const uint4*>(ptr)); };
+    auto ld8 = [&](const __bf16* ptr) { return __builtin_bit_cast(bf3_x8, *reinterpret_cast<const uint4*>(ptr)); };
     auto multiply = [&](int64_t k) {
         const __bf16* bf = pl + (k & 1) * bufsz;
 #pragma unroll
         for (int ks = 0; ks < R / 16; ++ks) {
-            const w3_bf16x8 ah = ld8(bf + aoff + 16 * ks), am = ld8(bf + aoff + O * P + 16 * ks), al = ld8(bf + aoff + 2 * O * P + 16 * ks);
-            w3_bf16x8 bh[TI], bm[TI], bl[TI];
+            const bf3_x8 ah = ld8(bf + aoff + 16 * ks), am = ld8(bf + aoff + O * P + 16 * ks), al = ld8(bf + aoff + 2 * O * P + 16 * ks);
+            bf3_x8 bh[TI], bm[TI], bl[TI];
 #pragma unroll
             for (int t = 0; t < TI; ++t) {
                 bh[t] = ld8(bf + boff[t] + 16 * ks); bm[t] = ld8(bf + boff[t] + I * P + 16 * ks); bl[t] = ld8(bf + boff[t] + 2 * I * P + 16 * ks);
@@ -925,6 +916,11 @@ extern "C" int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t strea
         kpgnn_linear_bn_desc f = {};
         f.N = d->N; f.n_dyn = d->n_dyn; f.O = d->O; f.I = d->I; f.x = d->x; f.w = d->w; f.bias = d->bias; f.y = d->y; f.w_transposed = d->w_transposed;
         return kpgnn_linear_bn(&f, stream);
+    }
+    if (blocked && (((uintptr_t)d->w) & 15) == 0) {
+        bool handled = false;
+        const int rc = linear3_blocked(d, s, &handled);                            // the bf16-split kernel, where it applies
+        if (handled || rc != KPGNN_OK) return rc;
     }
     if (d->I != 32 && d->I != 64 && d->I != 104 && d->I != 128)
         return fail(KPGNN_ELIMIT, "linear_fwd: wide outputs need I in {32, 64, 104, 128} (the k-loop is fully unrolled)");

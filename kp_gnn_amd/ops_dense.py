@@ -449,6 +449,13 @@ def _jk_native_ok(weight, bias, states):
             and all(st.shape == (N, H) and st.dtype == torch.float32 and st.is_contiguous() and st.data_ptr() % 16 == 0 for st in states))
 
 
+def _split_workspace(lib, O, I, group, device):
+    """Scratch for the bf16-split Linear kernels (kpgnn_linear_split_workspace_bytes): the copy of the weight in matrix-fragment
+    order, rebuilt by every call (the weights change every step); None when the kernels do not take the shape."""
+    nb = int(lib.kpgnn_linear_split_workspace_bytes(O, I, group))
+    return torch.empty(nb, dtype=torch.uint8, device=device) if nb > 0 else None
+
+
 class JKConcatLinear(torch.autograd.Function):
     """relu(cat(states, dim=1) W^T + b): the bodies' jumping-knowledge projection (models/GNNs.py:216-218, output_proj).
     Native path (kpgnn_linear_group_fwd / kpgnn_linear_fwd / kpgnn_linear_wgrad_group): the concatenation is never made - the
@@ -477,6 +484,9 @@ class JKConcatLinear(torch.autograd.Function):
             for l, st in enumerate(states):
                 d.x[l] = st.data_ptr()
             d.x_stride, d.w, d.bias, d.y, d.relu = H, weight.data_ptr(), _ptr(bias), y.data_ptr(), 1
+            ws = _split_workspace(lib, O, H, len(states), weight.device)     # (the bf16-split kernel's copy of W; None: fp32 kernel)
+            if ws is not None:
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
             with torch.cuda.device(weight.device):
                 _lib.check(lib.kpgnn_linear_group_fwd(ctypes.byref(d), _stream(y)), "kpgnn_linear_group_fwd")
             ctx.save_for_backward(weight, y, *states)
@@ -510,6 +520,9 @@ class JKConcatLinear(torch.autograd.Function):
                 d.x, d.x_stride, d.w, d.y, d.y_stride = dy.data_ptr(), O, weight.data_ptr(), G.data_ptr(), H
                 d.w_transposed, d.y_block_cols, d.y_block_stride = 1, H, N * H
                 d.x_mask = y.data_ptr()                       # dL/d(pre-activation) = dy where the saved output is > 0
+                wsx = _split_workspace(lib, H, O, S, dev)
+                if wsx is not None:
+                    d.workspace, d.workspace_bytes = wsx.data_ptr(), wsx.numel()
                 _lib.check(lib.kpgnn_linear_fwd(ctypes.byref(d), _stream(dy)), "kpgnn_linear_fwd")
                 if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
                     from . import ops

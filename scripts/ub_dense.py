@@ -74,13 +74,21 @@ g.N, g.O, g.I, g.group = N, H, H, S
 for l, t in enumerate(states):
     g.x[l] = t.data_ptr()
 g.x_stride, g.w, g.bias, g.y, g.relu = H, wj.data_ptr(), b.data_ptr(), yj.data_ptr(), 1
+wsl = torch.empty(int(lib.kpgnn_linear_split_workspace_bytes(H, H, S)), dtype=torch.uint8, device=dev)
+g.workspace, g.workspace_bytes = wsl.data_ptr(), wsl.numel()
 timeit("JK linear_group_fwd (9 states)", lambda: _lib.check(lib.kpgnn_linear_group_fwd(ctypes.byref(g), st), "lg"), 2.0 * N * H * H * S)
 G = torch.empty(S, N, H, device=dev)
 dl = _lib.LinearDesc()
 dl.N, dl.O, dl.I = N, S * H, H
 dl.x, dl.x_stride, dl.w, dl.y, dl.y_stride = dy.data_ptr(), H, wj.data_ptr(), G.data_ptr(), H
 dl.w_transposed, dl.y_block_cols, dl.y_block_stride, dl.x_mask = 1, H, N * H, yj.data_ptr()
+wsd = torch.empty_like(wsl)
+dl.workspace, dl.workspace_bytes = wsd.data_ptr(), wsd.numel()
 timeit("JK dX linear_wide (masked)", lambda: _lib.check(lib.kpgnn_linear_fwd(ctypes.byref(dl), st), "lw"), 2.0 * N * H * H * S)
+refy = torch.relu(torch.cat(states, 1).double() @ wj.double().t() + b.double())
+print(f"JK forward max error / max |y| against float64: {((yj.double() - refy).abs().max() / refy.abs().max()).item():.3e}")
+refg = (dy.double() * (yj > 0)) @ wj.double()
+print(f"JK dX max error / max |dX| against float64: {((G.permute(1, 0, 2).reshape(N, S * H).double() - refg).abs().max() / refg.abs().max()).item():.3e}")
 dwj = torch.empty(H, S * H, device=dev)
 dbj = torch.empty(H, device=dev)
 nbj = int(lib.kpgnn_wgrad_group_workspace_bytes(H, H, S))

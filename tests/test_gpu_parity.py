@@ -705,10 +705,11 @@ def test_linear_wgrad_pair_and_x_transform():
     _close(db[1], dy2.sum(0), "db1", rtol=2e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("N,H,S,O", [(4099, 104, 9, 104), (300, 32, 5, 64), (1000, 104, 2, 104), (2050, 64, 16, 128), (513, 96, 3, 32)])
+@pytest.mark.parametrize("N,H,S,O", [(4099, 104, 9, 104), (300, 32, 5, 64), (1000, 104, 2, 104), (2050, 64, 16, 128), (513, 96, 3, 32),
+                                     (9001, 104, 9, 104), (5000, 64, 3, 64), (4500, 128, 2, 128), (6000, 32, 5, 64), (4097, 96, 16, 32)])
 def test_jk_projection_native_vs_torch(N, H, S, O):
     """The bodies' jumping-knowledge projection relu(cat(h_list) W^T + b) (models/GNNs.py:216-218, :455-457) on the grouped-K
-    kernels - kpgnn_linear_group_fwd (K-loop over the state pointers, no concat), kpgnn_linear_fwd with the ReLU mask read on
+    kernels (N >= 4096: the bf16-split kernels of linear_bf3.hip; below: the fp32 matrix instruction) - kpgnn_linear_group_fwd (K-loop over the state pointers, no concat), kpgnn_linear_fwd with the ReLU mask read on
     load, kpgnn_linear_wgrad_group (S column blocks side by side) - against the reference's op sequence on the CPU: output,
     every state's gradient, dW, db.  Pre-activations within rounding of the ReLU kink are excluded from the comparison by
     construction: the CPU side applies the mask the GPU forward produced."""
