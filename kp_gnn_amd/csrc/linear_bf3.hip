@@ -14,6 +14,9 @@
 // instructions per k step - and waves 4-7 stage the NEXT state's three tiles meanwhile (requested two states ahead, split,
 // written as three row-major bf16 planes; 240-byte row pitch = conflict-free 16-byte fragment reads, 8-byte stores of 16
 // contiguous lanes cover 32 banks).  One barrier per state.  Mode 1 stages its tiles once and writes three output tiles per state.
+// Measured (s_memtime, [47450, 104] x 9 states, ~1.55 GHz under this load): a state costs the multiplying wave 4700-5000 cycles
+// (126 matrix instructions = 4032), the staging wave NEXT TO IT on the SIMD 6300 for ~300 vector instructions (alone: ~1500),
+// mode 1's 48 stores 1350: 86 / 88 us against 138 / 136 for the fp32-instruction kernels, W split included.
 #include "bf3.h"
 #include "kpgnn_common.h"
 
@@ -81,12 +84,12 @@ lin3_kernel(const L3Params p) {
         const int ptid = tid - 256;
         const int ncg = I >> 2;
         int prow[PF], pcg[PF];
-        bool pown[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int e = ptid + 256 * i;
-            pown[i] = e < ROWS * ncg;
-            prow[i] = pown[i] ? e / ncg : 0; pcg[i] = pown[i] ? e % ncg : 0;
+            // (tasks beyond the buffer repeat its last one - the same bytes stored twice - rather than guard the stores: eleven
+            //  guarded stores became eleven divergent branches with the split inside them)
+            const int e = min(ptid + 256 * i, ROWS * ncg - 1);
+            prow[i] = e / ncg; pcg[i] = e % ncg;
         }
         const uint32_t sbytes = (uint32_t)p.xstride * 4u;
         const int lim = (int)min((int64_t)ROWS - 1, N - 1 - rows0);       // last valid row of the block (>= 0)
@@ -121,12 +124,10 @@ lin3_kernel(const L3Params p) {
                 bf3_u2 h0, m0, l0, h1, m1, l1;
                 bf3_split2(bf3_f2{x.x, x.y}, h0, m0, l0);
                 bf3_split2(bf3_f2{x.z, x.w}, h1, m1, l1);
-                if (pown[i]) {
-                    __bf16* q = buf + prow[i] * PK + 4 * pcg[i];
-                    *reinterpret_cast<uint2*>(q) = make_uint2(bf3_pack(h0.x, h0.y), bf3_pack(h1.x, h1.y));
-                    *reinterpret_cast<uint2*>(q + ROWS * PK) = make_uint2(bf3_pack(m0.x, m0.y), bf3_pack(m1.x, m1.y));
-                    *reinterpret_cast<uint2*>(q + 2 * ROWS * PK) = make_uint2(bf3_pack(l0.x, l0.y), bf3_pack(l1.x, l1.y));
-                }
+                __bf16* q = buf + prow[i] * PK + 4 * pcg[i];
+                *reinterpret_cast<uint2*>(q) = make_uint2(bf3_pack(h0.x, h0.y), bf3_pack(h1.x, h1.y));
+                *reinterpret_cast<uint2*>(q + ROWS * PK) = make_uint2(bf3_pack(m0.x, m0.y), bf3_pack(m1.x, m1.y));
+                *reinterpret_cast<uint2*>(q + 2 * ROWS * PK) = make_uint2(bf3_pack(l0.x, l0.y), bf3_pack(l1.x, l1.y));
             }
         };
         __builtin_amdgcn_s_setprio(2);
@@ -172,17 +173,35 @@ lin3_kernel(const L3Params p) {
 #pragma unroll
     for (int m = 0; m < kL3Tiles; ++m)
         for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
-    // acc[m][v] of lane (c, kg): row 32 m + (v & 3) + 8 (v >> 2) + 4 kg of the block, column n
+    // acc[m][v] of lane (c, kg): row 32 m + (v & 3) + 8 (v >> 2) + 4 kg of the block, column n.  One scalar base per call and a
+    // running 32-bit lane offset (+1 or +5 rows): 48 separate row pointers and row tests - all loop invariant, so all hoisted -
+    // overflowed the scalar registers into vector lanes (3000 cycles per 48 stores).  Only the batch's last block tests rows.
+    const uint32_t lane_off = ((uint32_t)(4 * kg) * (uint32_t)p.ystride + (uint32_t)n) * 4u;
+    const uint32_t row1 = (uint32_t)p.ystride * 4u, row5 = 5u * row1;
+    const int lane_rows = (int)min((int64_t)ROWS, N - rows0) - 4 * kg;        // rows of the block below this lane's first one that exist
     auto store = [&](float* out, float b, bool relu) {
-        if (n < O) {
+        if (n >= O) return;
+        char* base = reinterpret_cast<char*>(out + rows0 * p.ystride);         // (scalar)
+        uint32_t off = lane_off;
+        if (rows0 + ROWS <= N) {                                               // (uniform)
 #pragma unroll
             for (int m = 0; m < kL3Tiles; ++m)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int64_t r = rows0 + 32 * m + (v & 3) + 8 * (v >> 2) + 4 * kg;
                     float val = acc[m][v] + b;
                     if (relu) val = fmaxf(val, 0.f);
-                    if (r < N) out[r * p.ystride + n] = val;
+                    *reinterpret_cast<float*>(base + off) = val;
+                    off += (v & 3) == 3 ? row5 : row1;
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kL3Tiles; ++m)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float val = acc[m][v] + b;
+                    if (relu) val = fmaxf(val, 0.f);
+                    if (32 * m + (v & 3) + 8 * (v >> 2) < lane_rows) *reinterpret_cast<float*>(base + off) = val;
+                    off += (v & 3) == 3 ? row5 : row1;
                 }
         }
     };
@@ -212,6 +231,10 @@ lin3_kernel(const L3Params p) {
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0[0], acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0[1], acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0[0], acc[m], 0, 0, 0);
+                    // (the next fragments' LDS reads FIRST, then the six matrix instructions: left alone the scheduler sinks the reads
+                    //  to the end of the group and the next group starts by waiting out their latency - 88 cycles per instruction)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     ah = nh; am = nm; al = nl;
                 }
