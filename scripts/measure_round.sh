@@ -16,6 +16,10 @@ run bench_qm9 --workload qm9 --cpu-graphs 64
 run bench_regular_b1 --workload regular --batch 1 --steps 50
 run bench_regular_b100 --workload regular --batch 100 --steps 10 --warmup 2 --num-batches 1 --no-cpu-baseline
 run bench_zinc_gd16 --workload zinc_gd16 --cpu-graphs 16 --num-batches 2
+run bench_strong1 --scaling strong --no-cpu-baseline --no-roofline
+timeout -k 10 200 python scripts/ub_dense.py > $R/ub_dense.txt 2>&1; echo "ub_dense rc=$?"
+UB_MATH=f32 timeout -k 10 200 python scripts/ub_dense.py > $R/ub_dense_f32.txt 2>&1; echo "ub_dense f32 rc=$?"
+timeout -k 10 200 python scripts/det_check.py > $R/det_check.txt 2>&1; echo "det_check rc=$?"
 cd /tmp && export TMPDIR=/tmp
 prof() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_$name -- $PB "$@" --no-cpu-baseline --no-roofline > $R/prof_$name.log 2>&1; echo "prof $name rc=$?"; }
 prof default --steps 20 --warmup 3
