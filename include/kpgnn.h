@@ -651,6 +651,12 @@ typedef struct kpgnn_linear_desc {
 int kpgnn_linear_fwd(const kpgnn_linear_desc* d, kpgnn_stream_t stream);
 /* Bytes of the split copy of `group` weight blocks of [O, I] (O, I <= 128) for the bf16-split kernels; 0 for shapes they do not take. */
 size_t kpgnn_linear_split_workspace_bytes(int32_t O, int32_t I, int32_t group);
+/* The split copies of up to 64 weight matrices in ONE launch (a body prepares all its MLPs' Linears, both orientations, at the
+ * start of a step; kpgnn_linear_bn then takes them with w_split_ready = 1 instead of splitting per call - 34 five-microsecond
+ * launches per step otherwise).  Element (k, n) of job i at w[n * wn + k * wk], n < O, k < I; frag: device,
+ * >= kpgnn_linear_split_workspace_bytes(O, I, 1), 16-B aligned. */
+typedef struct kpgnn_split_job { const float* w; int64_t wn, wk; int32_t O, I; void* frag; } kpgnn_split_job;
+int kpgnn_linear_split_many(const kpgnn_split_job* jobs, int32_t n, kpgnn_stream_t stream);
 
 /* y = act(sum_l x_l W[:, l*I:(l+1)*I]^T + b): nn.Linear over the concatenation of `group` (<= 16) states x_l [N,I] that live
  * in SEPARATE tensors - the bodies' jumping-knowledge projection `output_proj(torch.cat(h_list, dim=-1))`
@@ -706,6 +712,9 @@ typedef struct kpgnn_linear_bn_desc {
     const float* e_x; const float* e_mean; const float* e_invstd; const float* e_gamma; const float* e_beta;
     const float* o_mean; const float* o_invstd; const float* o_gamma; float* o_dgamma; float* o_dbeta;   /* pro 3 */
     const int32_t* n_dyn;       /* optional live-row count (device int32[1], <= N; kpgnn_wgrad_desc explains); NULL: all N rows */
+    int32_t math;               /* KPGNN_MATH_* (bf16-split product: N >= 4096, I <= 104, a workspace; pro >= 2 then needs xt) */
+    void* workspace; size_t workspace_bytes;   /* optional, 16-B aligned, >= kpgnn_linear_split_workspace_bytes(O, I, 1); NULL: fp32 kernel */
+    int32_t w_split_ready;      /* 1: workspace already holds the split copy of w in this orientation (kpgnn_linear_split_many) */
 } kpgnn_linear_bn_desc;
 
 int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t stream);

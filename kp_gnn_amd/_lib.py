@@ -11,6 +11,10 @@ MODE_GIN, MODE_GINPLUS, MODE_GCN, MODE_SUM = 0, 1, 2, 3
 c_i32, c_i64, c_f32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
 
 
+MATH_AUTO, MATH_F32 = 0, 1     # include/kpgnn.h KPGNN_MATH_*
+DENSE_MATH = MATH_AUTO          # what new dense descriptors ask for (ops_dense.set_dense_math)
+
+
 class KpgnnError(RuntimeError):
     pass
 
@@ -120,10 +124,6 @@ class ReduceJob(ctypes.Structure):
     _fields_ = [("slab", c_vp), ("nslab", c_i32), ("elems", c_i64), ("out", c_vp * 4), ("n_out", c_i64 * 4)]
 
 
-MATH_AUTO, MATH_F32 = 0, 1     # include/kpgnn.h KPGNN_MATH_*
-DENSE_MATH = MATH_AUTO          # what new dense descriptors ask for (ops_dense.set_dense_math)
-
-
 class WgradDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
@@ -151,8 +151,17 @@ class LinearBnDesc(ctypes.Structure):
         ("out_slot", c_vp),
         ("e_x", c_vp), ("e_mean", c_vp), ("e_invstd", c_vp), ("e_gamma", c_vp), ("e_beta", c_vp),
         ("o_mean", c_vp), ("o_invstd", c_vp), ("o_gamma", c_vp), ("o_dgamma", c_vp), ("o_dbeta", c_vp),
-        ("n_dyn", c_vp),
+        ("n_dyn", c_vp), ("math", c_i32), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+        ("w_split_ready", c_i32),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.math = DENSE_MATH
+
+
+class SplitJob(ctypes.Structure):
+    _fields_ = [("w", c_vp), ("wn", c_i64), ("wk", c_i64), ("O", c_i32), ("I", c_i32), ("frag", c_vp)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -304,6 +313,7 @@ SIGNATURES = {
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
     "kpgnn_linear_split_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
+    "kpgnn_linear_split_many": (ctypes.c_int, [ctypes.POINTER(SplitJob), c_i32, c_vp]),
     "kpgnn_linear_group_fwd": (ctypes.c_int, [ctypes.POINTER(LinearGroupDesc), c_vp]),
     "kpgnn_geo_theta_fwd": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "kpgnn_geo_theta_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),

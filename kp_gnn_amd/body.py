@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .layers.gine import GINEConv
 from .ops import DictPeripheral, embedding_rows, enc_tables, segment_pool, table_gather_sum
-from .ops_dense import JKConcatLinear, batch_norm_act, score_head
+from .ops_dense import JKConcatLinear, batch_norm_act, prepare_mlp_splits, score_head
 
 MAX_DICT_ROWS = 128  # peripheral dictionaries up to this many distinct tuples use the dictionary kernels
 
@@ -411,6 +411,7 @@ class GNN(_KHopBody):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
         x = self._inputs(data)
+        _prepare_splits(self.gnns, x)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list = [x]
@@ -462,6 +463,7 @@ class GNNPlus(_KHopBody):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
         x = self._inputs(data)
+        _prepare_splits(self.gnns, x)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list, last_h = [x], x
@@ -527,6 +529,7 @@ class GNNPrime(_KHopBody):
         edge_index, edge_attr, batch = data.edge_index, data.edge_attr, _get(data, "batch")
         pe_attr = _get(data, "pe_attr")
         x = self._inputs(data)
+        _prepare_splits(list(self.khop_gnns) + list(self.gins), x)
         periph = self._peripheral(data, x.size(0), x)
         vn = self._vn_init(batch, edge_index) if self.virtual_node else None
         h_list = [x]
@@ -556,6 +559,16 @@ class GNNPrime(_KHopBody):
 def make_GNN(args):
     """models/model_utils.py:8-14."""
     return {"KPGINPlus": GNNPlus, "KPGINPrime": GNNPrime}.get(args.model_name, GNN)
+
+
+def _prepare_splits(layers, x):
+    """The split copies of every layer MLP's weights for the bf16-split Linear kernels, one launch per forward
+    (ops_dense.prepare_mlp_splits); training mode on the device only - the fused MLP path is the only taker."""
+    if x.is_cuda and torch.is_grad_enabled():
+        mlps = [g.mlp for g in layers if g.training and isinstance(getattr(g, "mlp", None), nn.Sequential) and len(g.mlp) >= 5
+                and isinstance(g.mlp[0], nn.Linear) and isinstance(g.mlp[3], nn.Linear)]
+        if mlps:
+            prepare_mlp_splits(mlps, x.size(0))
 
 
 class GraphRegression(nn.Module):

@@ -66,6 +66,8 @@ hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 size_t linear3_workspace_bytes(int O, int I, int group);
 int linear3_group_fwd(const kpgnn_linear_group_desc* d, hipStream_t s, bool* handled);
 int linear3_blocked(const kpgnn_linear_desc* d, hipStream_t s, bool* handled);
+// the split copy of ONE weight matrix (element (k, n) at w[n * wn + k * wk]) in B-fragment order, for linear3_fused
+int linear3_split_w(const float* w, int64_t wn, int64_t wk, int O, int I, void* frag, hipStream_t s);
 
 // out_j[e] = sum_b slab[b][e] in block order (deterministic); the `elems` outputs are split over up to three
 // destination arrays of n0 / n1 / rest elements (table_grad.hip).

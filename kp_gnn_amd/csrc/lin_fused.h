@@ -389,5 +389,7 @@ int lin_launch_bn(const LinFParams& p, hipStream_t s);          // PRO 1, EPI 0
 int lin_launch_bwd_reduce(const LinFParams& p, hipStream_t s);  // PRO 2, EPI 2
 int lin_launch_bwd(const LinFParams& p, hipStream_t s);         // PRO 2, EPI 0
 int lin_launch_bwd2_reduce(const LinFParams& p, hipStream_t s); // PRO 3, EPI 2
+// linear_bf3_fused.hip: the same launches on the bf16 matrix cores (wfrag: linear3_split_w's copy of W)
+int linear3_fused(const LinFParams& p, int pro, int epi, const uint4* wfrag, hipStream_t s);
 
 }  // namespace kpgnn

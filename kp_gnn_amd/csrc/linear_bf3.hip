@@ -59,6 +59,30 @@ lin3_wsplit_kernel(const float* __restrict__ w, int64_t wn, int64_t wk, int64_t 
     q[128] = make_uint4(bf3_pack(lo[0].x, lo[0].y), bf3_pack(lo[1].x, lo[1].y), bf3_pack(lo[2].x, lo[2].y), bf3_pack(lo[3].x, lo[3].y));
 }
 
+// the same for up to 64 matrices in one launch (blockIdx.y = matrix): every Linear of a body's MLPs at the start of a step
+struct SplitMany { kpgnn_split_job j[64]; };
+__global__ void __launch_bounds__(256)
+lin3_wsplit_many_kernel(const SplitMany a) {
+    const kpgnn_split_job& q = a.j[blockIdx.y];
+    const int KS = (q.I + 15) / 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(t & 63);
+    const int64_t f = t >> 6;                       // strip * KS + ks
+    if (f >= 4 * KS) return;
+    const int ks = (int)(f % KS), strip = (int)(f / KS);
+    const int n = strip * 32 + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (n < q.O && k0 + j < q.I) ? q.w[(int64_t)n * q.wn + (int64_t)(k0 + j) * q.wk] : 0.f;
+    bf3_u2 h[4], m[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf3_split2(bf3_f2{v[2 * j], v[2 * j + 1]}, h[j], m[j], lo[j]);
+    uint4* o = reinterpret_cast<uint4*>(q.frag) + f * 3 * 64 + lane;
+    o[0] = make_uint4(bf3_pack(h[0].x, h[0].y), bf3_pack(h[1].x, h[1].y), bf3_pack(h[2].x, h[2].y), bf3_pack(h[3].x, h[3].y));
+    o[64] = make_uint4(bf3_pack(m[0].x, m[0].y), bf3_pack(m[1].x, m[1].y), bf3_pack(m[2].x, m[2].y), bf3_pack(m[3].x, m[3].y));
+    o[128] = make_uint4(bf3_pack(lo[0].x, lo[0].y), bf3_pack(lo[1].x, lo[1].y), bf3_pack(lo[2].x, lo[2].y), bf3_pack(lo[3].x, lo[3].y));
+}
+
 template <int KS, int MODE>
 __global__ void __launch_bounds__(512, 1)
 lin3_kernel(const L3Params p) {
@@ -292,6 +316,10 @@ bool lin3_shape_ok(int64_t N, int O, int I, int64_t xstride) {
 
 }  // namespace
 
+int linear3_split_w(const float* w, int64_t wn, int64_t wk, int O, int I, void* frag, hipStream_t s) {
+    return lin3_split_w(w, wn, wk, 0, 1, O, I, (uint4*)frag, s);
+}
+
 size_t linear3_workspace_bytes(int O, int I, int group) {
     if (O < 1 || O > 128 || I < 1 || I > 128 || group < 1 || group > 16) return 0;
     return (size_t)group * 4 * ((I + 15) / 16) * 3 * 64 * sizeof(uint4);
@@ -336,3 +364,24 @@ int linear3_blocked(const kpgnn_linear_desc* d, hipStream_t s, bool* handled) {
 }
 
 }  // namespace kpgnn
+
+extern "C" int kpgnn_linear_split_many(const kpgnn_split_job* jobs, int32_t n, kpgnn_stream_t stream) {
+    using namespace kpgnn;
+    KPGNN_REQUIRE(jobs != nullptr && n >= 1 && n <= 64, "linear_split_many: 1 <= n <= 64 jobs (n = %d)", n);
+    SplitMany a;
+    int kmax = 0;
+    for (int i = 0; i < 64; ++i) {
+        a.j[i] = jobs[i < n ? i : 0];
+        if (i < n) {
+            const kpgnn_split_job& q = jobs[i];
+            KPGNN_REQUIRE(q.w && q.frag && q.O >= 1 && q.O <= 128 && q.I >= 1 && q.I <= 128 && (((uintptr_t)q.frag) & 15) == 0,
+                          "linear_split_many: job %d: bad pointers or O=%d / I=%d beyond 128", i, q.O, q.I);
+            const int ks = (q.I + 15) / 16;
+            kmax = ks > kmax ? ks : kmax;
+        }
+    }
+    hipLaunchKernelGGL(lin3_wsplit_many_kernel, dim3((unsigned)((4 * kmax * 64 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    KPGNN_LAUNCH_CHECK("lin3_wsplit_many_kernel");
+    return KPGNN_OK;
+}
+

@@ -41,6 +41,18 @@ extern "C" int kpgnn_linear_bn(const kpgnn_linear_bn_desc* d, kpgnn_stream_t str
         p.e_x = d->e_x; p.e_mean = d->e_mean; p.e_invstd = d->e_invstd; p.e_gamma = d->e_gamma; p.e_beta = d->e_beta;
     }
     hipStream_t s = (hipStream_t)stream;
+    // the bf16-split kernels (linear_bf3_fused.hip) where they apply: a batch that fills the chip, a row that fits their LDS
+    // plan, the caller's scratch for the split copy of W
+    if (d->math != KPGNN_MATH_F32 && d->workspace && (((uintptr_t)d->workspace) & 15) == 0 && d->N >= 4096 && d->I <= 104 &&
+        d->workspace_bytes >= linear3_workspace_bytes(d->O, d->I, 1) && linear3_workspace_bytes(d->O, d->I, 1) > 0 &&
+        (d->pro < 2 || d->xt != nullptr) && (d->w_transposed || (((uintptr_t)d->w) & 15) == 0)) {
+        if (!d->w_split_ready) {
+            const int rc = d->w_transposed ? linear3_split_w(d->w, 1, d->O, d->O, d->I, d->workspace, s)       // w [I, O]
+                                           : linear3_split_w(d->w, d->I, 1, d->O, d->I, d->workspace, s);      // w [O, I]
+            if (rc != KPGNN_OK) return rc;
+        }
+        return linear3_fused(p, d->pro, d->epi, (const uint4*)d->workspace, s);
+    }
     switch (d->pro * 10 + d->epi) {
         case 0: return lin_launch_plain(p, s);
         case 1: return lin_launch_stats(p, s);

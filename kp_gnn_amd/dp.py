@@ -96,6 +96,8 @@ class FlatAdam:
 
     def step(self):
         from . import _lib
+        from .ops_dense import invalidate_splits
+        invalidate_splits()       # (the launch below changes the weights without bumping their version counters)
         dev = self.param.device
         if self.state is not None:
             with torch.cuda.device(dev):

@@ -249,11 +249,65 @@ def batch_norm_act(x, bn, relu=False, residual=None):
     return out
 
 
+# Split copies of the MLPs' weights for the bf16-split Linear kernels (kpgnn_linear_split_many): a body prepares ALL of them,
+# both orientations, with one launch at the start of its forward; kpgnn_linear_bn then finds them here instead of splitting per
+# call.  An entry serves the forward and the backward of the step that made it: the next forward overwrites it, and it is only
+# taken while the weight tensor has the version it was made from.
+_split_cache = {}
+
+
+def invalidate_splits():
+    """Forget the prepared split copies (an optimiser that updates weights without bumping their version calls this)."""
+    _split_cache.clear()
+
+
+def prepare_mlp_splits(mlps, num_rows):
+    """One launch for every Linear of the given Linear-BatchNorm-ReLU-Linear-BatchNorm-ReLU MLPs, in the orientation of the
+    forward (y = x W^T) and of the input gradient (dx = dy W).  No-op outside the bf16-split kernels' range."""
+    if num_rows < 4096 or _lib.DENSE_MATH == _lib.MATH_F32:
+        return
+    lib = _lib.load()
+    todo = []
+    for mlp in mlps:
+        for lin in (mlp[0], mlp[3]):
+            w = lin.weight
+            O, I = w.shape
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and O <= 104 and I <= 104 and O % 4 == 0 and I % 4 == 0):
+                continue
+            todo.append((w, 0, I, 1, O, I))        # forward: element (k, n) = w[n * I + k]
+            todo.append((w, 1, 1, I, I, O))        # dx = dy w: output column n = input feature, k = output feature: w[k * I + n]
+    if not todo:
+        return
+    dev = todo[0][0].device
+    sizes = [int(lib.kpgnn_linear_split_workspace_bytes(O, I, 1)) for (_, _, _, _, O, I) in todo]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    jobs = (_lib.SplitJob * len(todo))()
+    off = 0
+    for j, ((w, tr, wn, wk, O, I), nb) in enumerate(zip(todo, sizes)):
+        frag = buf[off:off + nb]
+        jobs[j].w, jobs[j].wn, jobs[j].wk, jobs[j].O, jobs[j].I, jobs[j].frag = w.data_ptr(), wn, wk, O, I, frag.data_ptr()
+        _split_cache[(w.data_ptr(), tr)] = (w._version, O, I, frag)
+        off += nb
+    with torch.cuda.device(dev):
+        for a in range(0, len(todo), 64):
+            n = min(64, len(todo) - a)
+            chunk = (_lib.SplitJob * n)(*jobs[a:a + n])
+            _lib.check(lib.kpgnn_linear_split_many(chunk, n, torch.cuda.current_stream(dev).cuda_stream), "kpgnn_linear_split_many")
+
+
 def _lin_bn(lib, dev, **kw):
     d = _lib.LinearBnDesc()
     for k, v in kw.items():
         setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
     d.n_dyn = dyn_ptr(kw["N"])
+    w = kw["w"]
+    hit = _split_cache.get((w.data_ptr(), 1 if kw.get("w_transposed", 0) else 0))
+    if hit is not None and hit[0] == w._version and hit[1] == kw["O"] and hit[2] == kw["I"]:
+        d.workspace, d.workspace_bytes, d.w_split_ready = hit[3].data_ptr(), hit[3].numel(), 1
+    else:
+        ws = _split_workspace(lib, kw["O"], kw["I"], 1, dev)          # (the bf16-split kernel's copy of W; None: fp32 kernel)
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):
         _lib.check(lib.kpgnn_linear_bn(ctypes.byref(d), torch.cuda.current_stream(dev).cuda_stream), "kpgnn_linear_bn")
 

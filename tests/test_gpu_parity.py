@@ -1291,7 +1291,12 @@ def _gpu_relu_masks(node):
 
 
 @pytest.mark.parametrize("N,I,O", [(4099, 104, 104), (1500, 64, 104), (47450, 104, 104), (33, 32, 32), (2048, 96, 96),
-                                   (2500, 128, 128), (1000, 104, 64), (32768, 104, 104), (17, 32, 32)])
+                                   (2500, 128, 128), (1000, 104, 64), (32768, 104, 104), (17, 32, 32),
+                                   # N >= 4096 and I, O <= 104: the bf16-split kernels of linear_bf3_fused.hip; (4100, 128, 128): the
+                                   # fp32 kernels' side of that border.  (N = 4096 x 128 x 128 is left out: the CPU REFERENCE is the
+                                   # ill-conditioned party there - its fp32 batch_norm gives 4.bias.grad to 4e-4 of float64 with 8
+                                   # threads and to 8e-3 with one, so the verdict depended on which tests had run before.)
+                                   (5000, 64, 104), (4500, 96, 96), (6001, 32, 32), (4200, 104, 64), (4100, 128, 128)])
 @pytest.mark.parametrize("follow_norm", [False, True, "fused", "fused_cell"])
 def test_fused_mlp_vs_torch(N, I, O, follow_norm):
     """kpgnn_linear_bn + slots: Linear-BN-ReLU-Linear-BN-ReLU (KPGINplus.py:25-30) in 3 + 5 launches against the same
