@@ -3,7 +3,7 @@
 // Contract: include/kpgnn.h, kpgnn_linear_bn with math = KPGNN_MATH_AUTO and a workspace; same PRO / EPI semantics, same
 // statistics slots as lin_fused_kernel, which stays the path for small batches and for KPGNN_MATH_F32.
 //
-// A block of 8 waves works through groups of 96 rows (blocks = CUs, ~2 groups each at the bench shape).  Waves 4-7 stage: the
+// A block of 8 waves works through groups of 32 rows (blocks = CUs, ~6 groups each at the bench shape).  Waves 4-7 stage: the
 // prologue arithmetic of PRO 1 / 2 / 3 happens on the float4 they fetched (PRO >= 2: two source tensors, the transformed rows
 // also leave for the weight-gradient kernel), then the split into three bf16 planes.  Waves 0-3 multiply: the 32-column strip
 // of the pre-split W stays in 21 register fragments for the whole launch; the accumulators hold an output tile with a lane per
@@ -15,9 +15,9 @@
 namespace kpgnn {
 namespace {
 
-constexpr int kF3Rows = 96;
+constexpr int kF3Rows = 32;       // rows per pipeline step (one 32-row tile: 96-row steps ran 17-35 us per launch, stage and multiply of a block's ~2 steps barely overlapping)
 constexpr int f3_pitch(int ks) { return ks <= 7 ? 120 : 136; }
-constexpr int f3_buf(int ks) { return 3 * kF3Rows * f3_pitch(ks); }      // bf16 per buffer (three planes of 96 rows)
+constexpr int f3_buf(int ks) { return 3 * kF3Rows * f3_pitch(ks); }      // bf16 per buffer (three planes of one group)
 
 template <int KS, int PRO, int EPI>
 __global__ void __launch_bounds__(512, 1)
@@ -107,9 +107,9 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) prow[i] = min(rl + i * RL, ROWS - 1);
         const uint32_t sbytes = (uint32_t)I * 4u;                 // (x, x2, xt are contiguous [N, I])
-        float4 pv[PF], pu[PF];
+        float4 pvs[4][PF], pus[4][PF];                    // four groups' requests in flight (a group is ~1 us of matrix work, a round trip 2-3)
         // (unconditional requests: clamped rows, clamped group index - see wgrad.hip)
-        auto issue = [&](int g) {
+        auto issue = [&](int g, float4 (&pv)[PF], float4 (&pu)[PF]) {
             g = min(g, G - 1);
             const int64_t r0 = ((int64_t)blockIdx.x + (int64_t)g * gridDim.x) * ROWS;
             const int lim = (int)min((int64_t)ROWS - 1, p.N - 1 - r0);
@@ -122,7 +122,7 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
                 if (PRO >= 2) pu[i] = *reinterpret_cast<const float4*>(up + off);
             }
         };
-        auto commit = [&](int g) {
+        auto commit = [&](int g, float4 (&pv)[PF], float4 (&pu)[PF]) {
             if (g >= G) return;                                   // (uniform; no request inside)
             const int64_t r0 = ((int64_t)blockIdx.x + (int64_t)g * gridDim.x) * ROWS;
             const int lim = (int)min((int64_t)ROWS - 1, p.N - 1 - r0);
@@ -166,14 +166,25 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
             }
         };
         __builtin_amdgcn_s_setprio(2);
-        issue(0);
-        commit(0);
-        issue(1);
+        issue(0, pvs[0], pus[0]);
+        issue(1, pvs[1], pus[1]);
+        issue(2, pvs[2], pus[2]);
+        issue(3, pvs[3], pus[3]);
+        commit(0, pvs[0], pus[0]);
+        issue(4, pvs[0], pus[0]);
         __syncthreads();
-        for (int g = 0; g < G; ++g) {                             // group g + 1 is staged while group g is multiplied
-            commit(g + 1);
-            issue(g + 2);
-            __syncthreads();
+        // group g + 1 is staged while group g is multiplied; its register set then takes the requests of group g + 5 (set = group
+        // mod 4: the loop is unrolled by four so that the set is a compile-time choice)
+        for (int g0 = 0; g0 < G; g0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u;
+                if (g < G) {                                      // (uniform)
+                    commit(g + 1, pvs[(u + 1) & 3], pus[(u + 1) & 3]);
+                    issue(g + 5, pvs[(u + 1) & 3], pus[(u + 1) & 3]);
+                    __syncthreads();
+                }
+            }
         }
         return;
     }
@@ -211,7 +222,7 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
         const bool full = r0 + ROWS <= p.N;           // (uniform)
         const __bf16* ap0 = pl + (g & 1) * BUF + c * PK + 8 * kg;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+        for (int m = 0; m < ROWS / 32; ++m) {
             f32x16 acc;
             for (int v = 0; v < 16; ++v) acc[v] = 0.f;
             float ex[16];
@@ -244,7 +255,7 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
                     ah = nh; am = nm; al = nl;
                 }
             }
-            if (m == 2) __syncthreads();              // these waves are done with buffer g & 1; group g + 1 is staged
+            if (m == ROWS / 32 - 1) __syncthreads();  // these waves are done with buffer g & 1; group g + 1 is staged
             if (strip && col) {
                 uint32_t off = lane_off + (uint32_t)(32 * m) * row1;
                 asm volatile("" : "+v"(off));
