@@ -280,6 +280,11 @@ typedef struct kpgnn_agg_fwd_desc {
      * slab is staged once per (graph, hop) block and every neighbour row comes from there - the kernel for dense K-hop
      * neighbourhoods (run_simulation.py's 3-regular n = 1280 graphs: 582 pairs per node), where the plain gather is L2-bound. */
     const int32_t* graph_ptr; int32_t num_graphs; int32_t max_graph_nodes;
+    /* Optional, with a fused combine and a given theta: hout[i,:] = hinit[i,:] + sum_k ... (device [N,D] contiguous; may be hout
+     * itself).  This is what makes the launch the PULL form of the backward gather: with rowptr / col keyed by (source, hop),
+     * x_slot[k] = hop k's slab of dL/dS of the layer k + 1 steps later, mode SUM, theta = 1, it writes a state's whole gradient
+     * in one pass - every later reader's share plus what hinit already holds - instead of one read-modify-write per reader. */
+    const float* hinit;
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

@@ -82,6 +82,7 @@ struct FwdParams {
     const float* alphas;        // geometric combine computed in-kernel (theta is then this launch's OUTPUT via theta_out)
     float* theta_out;
     float* hout;
+    const float* hinit;         // fused combine: initial value of the hop sum ([N,D], may alias hout) or NULL
     const float* xbias;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     const float* xs[16];        // per-hop inputs (x == NULL)
@@ -164,6 +165,7 @@ agg_fwd_kernel(const FwdParams p) {
         if (i >= N_live) continue;          // whole sub-group leaves together
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
+        if (!FAST && p.hinit && col_ok) hsum = V<VEC>::load(p.hinit + i * (int64_t)D + c0);       // (pull form of the backward gather)
         // The waves of this kernel sit in s_waitcnt 85 % of their cycles (PMC, profiles/r01): per hop there were three
         // DEPENDENT round trips (row pointer -> pair list -> neighbour rows, then uid -> dictionary row).  So the node's
         // K+1 row pointers, its K dictionary ids and its whole pair list (all hops, one chunk of G pairs at a time -
@@ -726,7 +728,8 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         const int rc = agg_lds_fwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
     }
-    {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
+    KPGNN_REQUIRE(!d->hinit || (combine && !d->alphas), "aggregate_fwd: hinit needs a fused combine with a given theta");
+    if (!d->hinit) {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
         bool handled = false;
         int rc = d->n_dyn ? KPGNN_OK : agg_narrow_fwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
@@ -750,7 +753,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.x = d->x; p.x_sn = d->x_sn; p.x_sk = d->x_sk;
     p.table0 = d->table0; p.tablek = d->tablek;
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
-    p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.xbias = d->xbias;
+    p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.hinit = d->hinit; p.xbias = d->xbias;
     p.alphas = nullptr; p.theta_out = nullptr;
     if (d->alphas) {
         if (p.lds_theta) { p.alphas = d->alphas; p.theta_out = const_cast<float*>(d->theta); }   // theta staged in LDS: computed there
@@ -769,7 +772,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     const void* slot_align = (const void*)(slot_bits | 16);   // synthetic address carrying that alignment (never dereferenced)
     if ((uint64_t)d->N * (uint64_t)d->x_sn * 4u >= (1ull << 32))
         return fail(KPGNN_ELIMIT, "aggregate_fwd: N * x row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->x_sn);
-    const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->xbias, d->periph ? nullptr : d->ptab},
+    const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->hinit, d->xbias, d->periph ? nullptr : d->ptab},
                              {d->x_sn, d->x ? d->x_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
                               d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;

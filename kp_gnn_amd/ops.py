@@ -311,6 +311,45 @@ def aggregate_fwd_raw(csr, k_act, mode, x, table0, tablek, periph, eps, theta, x
     return out, pre
 
 
+PULL_GATHER = True      # (tests switch it off to compare with the read-modify-write form of the backward gather)
+_ones_cache = {}
+
+
+def khop_pull_gather(csr, slabs, hinit):
+    """A state's whole K-hop gradient in ONE launch (kpgnn_aggregate_fwd with the (source, hop)-keyed CSR, mode SUM, theta = 1
+    and `hinit`): out[i] = hinit[i] + sum_k sum_{j in N_k(i)} slabs[k][j], where slabs[k] is hop k's [N,D] slab of dL/dS of the
+    layer that read the state at hop slot k.  Replaces one read-modify-write of the state's gradient per reader (36 per step
+    at K = L = 8: agg_bwd moved 273 MB per launch for 183 MB of gathered rows) by one write per state."""
+    lib = _lib.load()
+    K = len(slabs)
+    N, D = slabs[0].shape
+    dev = slabs[0].device
+    key = (dev, D)
+    ones = _ones_cache.get(key)
+    if ones is None:
+        ones = _ones_cache[key] = torch.ones((16, D), dtype=torch.float32, device=dev)
+    out = hinit if hinit is not None else torch.empty((N, D), dtype=torch.float32, device=dev)
+    d = _lib.AggFwdDesc()
+    d.N, d.K, d.D, d.K_csr, d.mode = N, K, D, csr.K, MODE_SUM
+    d.n_dyn = dyn_ptr(N)
+    d.use_tables = 0
+    d.rowptr, d.col, d.code = csr.rowptr_src.data_ptr(), csr.col_src.data_ptr(), csr.code_src.data_ptr()
+    d.x_sn = D
+    for k, t in enumerate(slabs):
+        assert t.shape == (N, D) and t.is_contiguous() and t.dtype == torch.float32
+        d.x_slot[k] = t.data_ptr()
+    d.theta, d.hout, d.hinit = ones.data_ptr(), out.data_ptr(), _ptr(hinit)
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(out)), "kpgnn_aggregate_fwd (pull gather)")
+        if _timer is not None:
+            e1.record()
+            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 1, 0, extra_nd=1 + (hinit is not None)), e0, e1))
+    return out
+
+
 def aggregate_bwd_raw(csr, k_act, mode, g, eps, n_code0, n_codek, want_tables, slots=False, slot_bufs=None, gx_accum=None):
     """Launch kpgnn_aggregate_bwd on g = dL/dS.  Returns (gx, gtable0, gtablek); with slots=True gx is a list of
     k contiguous [N,D] tensors (one per hop slot) instead of one [N,k,D] tensor; slot_bufs[k] (a [N,D] tensor or None)
@@ -850,21 +889,50 @@ class KHopAggregate(torch.autograd.Function):
             b = ctx.x_cell.buf
             if b.is_contiguous() and b.numel() == g.numel() and b.dtype == torch.float32:
                 xbuf = b
+        # --- pull form (KP-GIN+ history pattern, large batches): this layer's hop slabs of g are parked with the states it read
+        #     as slots >= 1; the state it read as slot 0 - whose last reader it is - gets its WHOLE gradient from one gather over
+        #     the slabs later layers parked for it, this layer's hop-0 slab and whatever share the cell already holds
+        pull = (PULL_GATHER and ctx.n_slots > 0 and ctx.cells is not None and mode == MODE_GINPLUS and not tables_in_gather and eps is None
+                and g.dtype == torch.float32 and g.shape[0] >= 4096 and g.shape[2] % 4 == 0 and k_act <= 16
+                and all(g[:, k].is_contiguous() for k in range(k_act)))
+        if pull:
+            for k in range(1, k_act):
+                ctx.cells[k].park_slab(k, g[:, k])
+            c0 = ctx.cells[0]
+            pend = c0.take_slabs()
+            top = max(pend) if pend else 0
+            zeros = None
+            slabs = [g[:, 0]]
+            for h in range(1, top + 1):
+                t = pend.get(h)
+                if t is None:            # (a hop nobody parked - a pruned backward pass: gathered from zeros)
+                    zeros = torch.zeros_like(slabs[0]) if zeros is None else zeros
+                    t = zeros
+                slabs.append(t)
+            hb = c0.buf
+            hinit = hb if (hb is not None and hb.is_contiguous() and hb.dtype == torch.float32 and tuple(hb.shape) == tuple(slabs[0].shape)) else None
+            total = khop_pull_gather(csr, slabs[:16], hinit)
+            if hb is not None and hinit is None:
+                total = total + hb.view_as(total)          # (odd layout: add the parked share the plain way)
+            c0.buf = None
+            return (None, gt0, gtk, gperiph, None, _finish_gtheta(ctx, gtheta, theta, galphas_done, k_act), None, gdict, None, None, None,
+                    None, None, total, *([None] * (k_act - 1)))
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx), gx_accum=xbuf)
+        if ctx.n_slots > 0 and ctx.cells is not None:
+            pend = ctx.cells[0].take_slabs()      # (later layers ran the pull form, this one could not: their slabs for ITS slot-0 state)
+            if pend:
+                zeros = torch.zeros_like(next(iter(pend.values())))
+                extra = khop_pull_gather(csr, [pend.get(h, zeros) for h in range(0, max(pend) + 1)], None)
+                gx = list(gx)
+                gx[0] = gx[0] + extra
         if ctx.x_cell is not None:
             if xbuf is None and ctx.x_cell.buf is not None and ctx.needs_input_grad[0]:
                 gx = gx + ctx.x_cell.buf.view_as(gx)     # (odd layout: add the parked share the plain way)
             ctx.x_cell.buf = None
         if tables_in_gather:
             gt0, gtk = a0, ak
-        if gtheta is not None and ctx.alphas is not None and not galphas_done:   # d/dalphas through theta (geo_theta.hip)
-            galpha = torch.empty_like(ctx.alphas)
-            lib = _lib.load()
-            with torch.cuda.device(galpha.device):
-                _lib.check(lib.kpgnn_geo_theta_bwd(ctx.alphas.data_ptr(), theta.data_ptr(), gtheta.data_ptr(), k_act,
-                                                   ctx.alphas.numel(), galpha.data_ptr(), _stream(galpha)), "kpgnn_geo_theta_bwd")
-            gtheta = galpha
+        gtheta = _finish_gtheta(ctx, gtheta, theta, galphas_done, k_act)
         geps = None
         if eps is not None and ctx.needs_input_grad[4] and mode == MODE_GIN:
             refuse_dynamic_rows("the eps gradient (framework sum over rows)", g.shape[0])
@@ -879,6 +947,18 @@ class KHopAggregate(torch.autograd.Function):
                     *_slot_grads(ctx, gx))
         return (gx if ctx.needs_input_grad[0] else None, gt0, gtk, gperiph, geps, gtheta, None, gdict,
                 None, None, None, None, None)
+
+
+def _finish_gtheta(ctx, gtheta, theta, galphas_done, k_act):
+    """d/dalphas through theta (geo_theta.hip) when the finishing launch has not already produced it."""
+    if gtheta is not None and ctx.alphas is not None and not galphas_done:
+        galpha = torch.empty_like(ctx.alphas)
+        lib = _lib.load()
+        with torch.cuda.device(galpha.device):
+            _lib.check(lib.kpgnn_geo_theta_bwd(ctx.alphas.data_ptr(), theta.data_ptr(), gtheta.data_ptr(), k_act,
+                                               ctx.alphas.numel(), galpha.data_ptr(), _stream(galpha)), "kpgnn_geo_theta_bwd")
+        return galpha
+    return gtheta
 
 
 def _backward_pass_id():
@@ -898,10 +978,24 @@ class _SlotGradCell:
     no reader of ITS pass ever collects; the parked buffer is therefore tagged with the pass that wrote it
     (torch._C._current_graph_task_id()) and reads from any other pass see an empty cell - a stale share is never added to
     a later pass's gradient (tests/test_gpu_parity.py::test_gradient_cells_survive_a_partial_backward)."""
-    __slots__ = ("_buf", "_task")
+    __slots__ = ("_buf", "_task", "_pend", "_ptask")
 
     def __init__(self):
         self._buf, self._task = None, -1
+        self._pend, self._ptask = None, -1
+
+    # Pull form of the backward gather (khop_pull_gather): a later reader of the state does not add its share into `buf` -
+    # it leaves the hop slab of ITS dL/dS here, keyed by the hop slot it read the state at, and the state's last reader
+    # gathers from all of them in one launch.  Same pass tagging as `buf`.
+    def park_slab(self, hop, slab):
+        if self._pend is None or self._ptask != _backward_pass_id():
+            self._pend, self._ptask = {}, _backward_pass_id()
+        self._pend[hop] = slab
+
+    def take_slabs(self):
+        p = self._pend if (self._pend is not None and self._ptask == _backward_pass_id()) else {}
+        self._pend, self._ptask = None, -1
+        return p
 
     @property
     def buf(self):

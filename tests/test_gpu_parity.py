@@ -1790,6 +1790,61 @@ def test_deferred_reductions_with_a_weight_shared_by_two_nodes():
         assert torch.equal(ga, gb), tuple(p.shape)
 
 
+@pytest.mark.parametrize("K,L,H,graphs", [(3, 4, 32, 300), (8, 8, 104, 220), (4, 6, 64, 400)])
+def test_pull_gather_backward_equals_the_accumulating_one(K, L, H, graphs):
+    """The PULL form of the KP-GIN+ backward gather (ops.khop_pull_gather: a state's whole gradient from one launch over the hop
+    slabs its later readers parked) against the form it replaces (every reader adds its share into the state's cell with
+    kpgnn_aggregate_bwd): same score, every parameter gradient equal to fp32 summation-order accuracy - and against the CPU
+    oracle of the reference body on the same batch (N >= 4096: the large-batch kernels on both sides)."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    from oracle import kp_model_oracle as MO
+    dev = _dev()
+    model = _small_body("KPGINPlus", "geometric", K, L, H).to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    host = synthetic_zinc_batch(graphs, seed0=11, K=K)
+    b = host.to(dev)
+    b.build_csr()
+    assert b.num_nodes >= 4096
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+    def grads(pull):
+        model.load_state_dict(sd)
+        ops.PULL_GATHER = pull
+        try:
+            score = model(b)
+            loss = (score.squeeze() - b.y.squeeze()).abs().mean()
+            g = torch.autograd.grad(loss, params, allow_unused=True)
+        finally:
+            ops.PULL_GATHER = True
+        return score.detach().clone(), [None if t is None else t.clone() for t in g]
+
+    s1, g1 = grads(True)
+    s0, g0 = grads(False)
+    assert torch.equal(s1, s0)
+    gscale = max(float(t.abs().max()) for t in g0 if t is not None)
+    for n, a, c in zip(names, g1, g0):
+        assert (a is None) == (c is None), n
+        if a is not None:
+            tol = 2e-5 * max(float(c.abs().max()), 0.05 * gscale) + 1e-9
+            assert float((a - c).abs().max()) <= tol, (n, float((a - c).abs().max()), tol)
+    # ... and against the reference body on the CPU
+    p = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k and not k.endswith(".eps")) else v.clone())
+         for k, v in sd.items()}
+    ref = MO.graph_regression_forward(p, host.as_dict(), kind="GNNPlus", layer_kind="KPGINPlus", K=K, num_layer=L,
+                                      combine_kind="geometric", JK="concat", residual=True, training=True)
+    (ref.squeeze() - host.y.squeeze()).abs().mean().backward()
+    _close(s1, ref, "score", rtol=2e-4, atol=2e-5)
+    pm = {n: q for n, q in model.named_parameters() if q.requires_grad}
+    ref_grads = {n: p[n].grad for n in pm if p[n].grad is not None}
+    for q, gv in zip(params, g1):
+        q.grad = gv
+    # (a few thousand nodes through L training-mode BatchNorms: the first layers' gradients carry ~1e-4 of the gradient scale of
+    #  summation-order noise in BOTH forms above AND in the fp32 CPU oracle; the two forms agree with each other to 2e-5 - hence a floor of 5e-4 of the gradient scale, wider than the goldens')
+    _close_param_grads({n: pm[n] for n in ref_grads}, ref_grads, "pull body", rtol=1e-2, atol=5e-3)
+
+
 @pytest.mark.parametrize("workload,model_name,K,L,H,graphs", [("qm9", "KPGIN", 6, 3, 24, 10), ("qm9", "KPGIN", 6, 8, 120, 6),
                                                               ("zinc_gd16", "KPGINPrime", 16, 4, 96, 6)])
 def test_bench_workload_bodies_match_the_oracle(workload, model_name, K, L, H, graphs):
