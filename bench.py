@@ -561,10 +561,17 @@ def main():
                                                   "frac": round(top / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             g = s.get("agg_bwd")
             if g:
-                out["roofline_bwd"] = {"bound": "hbm", "kernel": "agg_bwd_kernel", "achieved": round(g["gbps"], 1),
+                # (KP-GIN+ at N >= 4096: the pull form - agg_fwd_kernel over the (source, hop)-keyed CSR, ops.khop_pull_gather;
+                #  elsewhere agg_bwd_kernel)
+                pull = args.model == "KPGINPlus" and args.combine == "geometric" and args.dtype == "f32" and not args.dense_peripheral \
+                    and b0.num_nodes >= 4096
+                out["roofline_bwd"] = {"bound": "hbm", "kernel": "agg_fwd_kernel (pull form of the backward gather)" if pull else "agg_bwd_kernel",
+                                       "achieved": round(g["gbps"], 1),
                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(g["gbps"] / HBM_PEAK_GBPS, 4),
+                                       "traffic": None,
                                        "launches": g["launches"], "avg_launch_ms": round(g["avg_ms"], 4),
                                        "algorithmic_bytes_per_launch": int(g["bytes_per_launch"])}
+                out["roofline_bwd"].update(pmc_traffic(args, "agg_pull_kernel" if pull else "agg_bwd_kernel"))
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v for k, v in model.state_dict().items()}
             log(f"cpu baseline: oracle on {threads} host threads ...")

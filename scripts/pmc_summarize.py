@@ -23,7 +23,18 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"(\w+_kernel)", name)
-    return m.group(1) if m else name.split("(")[0][:60]
+    if not m:
+        return name.split("(")[0][:60]
+    k = m.group(1)
+    if k == "agg_fwd_kernel":
+        # agg_fwd_kernel<VEC, G, GCN, TAB, FAST, BF>: the table-less non-FAST instantiation is, in the KP-GIN+ workloads, the PULL
+        # form of the backward gather (ops.khop_pull_gather) - kept apart from the forward launches it would be averaged with
+        a = re.search(r"agg_fwd_kernel<([^>]*)>", name)
+        if a:
+            t = [x.strip() for x in a.group(1).split(",")]
+            if len(t) >= 5 and t[3] == "0" and t[4] == "false":
+                return "agg_pull_kernel"
+    return k
 
 
 def load(d):
