@@ -165,7 +165,6 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
                 *reinterpret_cast<uint2*>(q + 2 * ROWS * PK) = make_uint2(bf3_pack(l0.x, l0.y), bf3_pack(l1.x, l1.y));
             }
         };
-        __builtin_amdgcn_s_setprio(2);
         issue(0, pvs[0], pus[0]);
         issue(1, pvs[1], pus[1]);
         issue(2, pvs[2], pus[2]);
@@ -190,6 +189,9 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
     }
 
     // ---- multiplying waves: output columns [32 wave, 32 wave + 32)
+    // (here the multiplying waves are the critical path - 1620 cycles of matrix work + the epilogue per group against ~1300 of
+    //  staging - so THEY get the SIMD's vector issue first; in wgrad.hip it is the other way round)
+    __builtin_amdgcn_s_setprio(2);
     const int n = wave * 32 + c;
     const bool strip = wave * 32 < O;                 // (uniform)
     const bool col = n < O;
@@ -229,11 +231,18 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
             if (EPI == 2 && strip && col) {
                 uint32_t off = lane_off + (uint32_t)(32 * m) * row1;
                 asm volatile("" : "+v"(off));          // (opaque: otherwise all 48 offsets of a group are hoisted out of the group loop)
+                if (full) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const bool in = full || 32 * m + (v & 3) + 8 * (v >> 2) < lane_rows;
-                    ex[v] = in ? *reinterpret_cast<const float*>(xb + off) : 0.f;
-                    off += (v & 3) == 3 ? row5 : row1;
+                    for (int v = 0; v < 16; ++v) {
+                        ex[v] = *reinterpret_cast<const float*>(xb + off);
+                        off += (v & 3) == 3 ? row5 : row1;
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        ex[v] = 32 * m + (v & 3) + 8 * (v >> 2) < lane_rows ? *reinterpret_cast<const float*>(xb + off) : 0.f;
+                        off += (v & 3) == 3 ? row5 : row1;
+                    }
                 }
             }
             if (strip) {
@@ -259,19 +268,39 @@ lin3f_kernel(LinFParams p, const uint4* __restrict__ wfrag) {
             if (strip && col) {
                 uint32_t off = lane_off + (uint32_t)(32 * m) * row1;
                 asm volatile("" : "+v"(off));
+                // (the tile's 16 values of this lane's column are summed in fp32, in row order, and join the fp64 column sums once
+                //  per tile: 48 fp64 operations per tile made the epilogue longer than the tile's 42 matrix instructions - 1900
+                //  against 1620 cycles; a 16-term fp32 partial carries ~1e-7 of unbiased rounding into sums of thousands of them)
+                float t0 = 0.f, t1 = 0.f;
+                if (full) {                            // (uniform: every group but the batch's last - no row tests, no exec masks)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const bool in = full || 32 * m + (v & 3) + 8 * (v >> 2) < lane_rows;
-                    float val = acc[v] + bias;
-                    if (EPI == 2) {
-                        const float xh = (ex[v] - em) * ei;
-                        if (fmaf(xh, eg, eb) <= 0.f) val = 0.f;
-                        if (in) { s0 += val; s1 = fma((double)val, (double)xh, s1); }
+                    for (int v = 0; v < 16; ++v) {
+                        float val = acc[v] + bias;
+                        if (EPI == 2) {
+                            const float xh = (ex[v] - em) * ei;
+                            if (fmaf(xh, eg, eb) <= 0.f) val = 0.f;
+                            t0 += val; t1 = fmaf(val, xh, t1);
+                        }
+                        if (EPI == 1) { t0 += val; t1 = fmaf(val, val, t1); }
+                        *reinterpret_cast<float*>(yb + off) = val;
+                        off += (v & 3) == 3 ? row5 : row1;
                     }
-                    if (EPI == 1 && in) { s0 += val; s1 = fma((double)val, (double)val, s1); }
-                    if (in) *reinterpret_cast<float*>(yb + off) = val;
-                    off += (v & 3) == 3 ? row5 : row1;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const bool in = 32 * m + (v & 3) + 8 * (v >> 2) < lane_rows;
+                        float val = acc[v] + bias;
+                        if (EPI == 2) {
+                            const float xh = (ex[v] - em) * ei;
+                            if (fmaf(xh, eg, eb) <= 0.f) val = 0.f;
+                            if (in) { t0 += val; t1 = fmaf(val, xh, t1); }
+                        }
+                        if (EPI == 1 && in) { t0 += val; t1 = fmaf(val, val, t1); }
+                        if (in) *reinterpret_cast<float*>(yb + off) = val;
+                        off += (v & 3) == 3 ? row5 : row1;
+                    }
                 }
+                if (EPI != 0) { s0 += (double)t0; s1 += (double)t1; }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
