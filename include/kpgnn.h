@@ -285,6 +285,7 @@ typedef struct kpgnn_agg_fwd_desc {
      * x_slot[k] = hop k's slab of dL/dS of the layer k + 1 steps later, mode SUM, theta = 1, it writes a state's whole gradient
      * in one pass - every later reader's share plus what hinit already holds - instead of one read-modify-write per reader. */
     const float* hinit;
+    const float* hinit2;        /* a second addend of the same kind (the pull form: the residual branch's share) or NULL */
 } kpgnn_agg_fwd_desc;
 
 int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t stream);

@@ -33,7 +33,7 @@ class AggFwdDesc(ctypes.Structure):
         ("ptab", c_vp), ("uid", c_vp), ("uid_stride", c_i64),
         ("x_slot", c_vp * 16), ("n_dict", c_i32), ("alphas", c_vp), ("storage", c_i32),
         ("n_dyn", c_vp),
-        ("graph_ptr", c_vp), ("num_graphs", c_i32), ("max_graph_nodes", c_i32), ("hinit", c_vp),
+        ("graph_ptr", c_vp), ("num_graphs", c_i32), ("max_graph_nodes", c_i32), ("hinit", c_vp), ("hinit2", c_vp),
     ]
 
 

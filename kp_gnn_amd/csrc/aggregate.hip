@@ -83,6 +83,7 @@ struct FwdParams {
     float* theta_out;
     float* hout;
     const float* hinit;         // fused combine: initial value of the hop sum ([N,D], may alias hout) or NULL
+    const float* hinit2;        // ... and a second addend ([N,D]) or NULL
     const float* xbias;
     const float* ptab; const int32_t* uid; int64_t uid_stride;
     const float* xs[16];        // per-hop inputs (x == NULL)
@@ -166,6 +167,7 @@ agg_fwd_kernel(const FwdParams p) {
         const int32_t* rp = p.rowptr + i * p.K_csr;
         V<VEC> hsum = V<VEC>::zero();
         if (!FAST && p.hinit && col_ok) hsum = V<VEC>::load(p.hinit + i * (int64_t)D + c0);       // (pull form of the backward gather)
+        if (!FAST && p.hinit2 && col_ok) hsum.add(V<VEC>::load(p.hinit2 + i * (int64_t)D + c0));
         // The waves of this kernel sit in s_waitcnt 85 % of their cycles (PMC, profiles/r01): per hop there were three
         // DEPENDENT round trips (row pointer -> pair list -> neighbour rows, then uid -> dictionary row).  So the node's
         // K+1 row pointers, its K dictionary ids and its whole pair list (all hops, one chunk of G pairs at a time -
@@ -728,8 +730,8 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
         const int rc = agg_lds_fwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
     }
-    KPGNN_REQUIRE(!d->hinit || (combine && !d->alphas), "aggregate_fwd: hinit needs a fused combine with a given theta");
-    if (!d->hinit) {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
+    KPGNN_REQUIRE((!d->hinit && !d->hinit2) || (combine && !d->alphas), "aggregate_fwd: hinit / hinit2 need a fused combine with a given theta");
+    if (!d->hinit && !d->hinit2) {   // narrow rows (KP-GIN's hidden / K): one thread per output element, all hops of a node in parallel
         bool handled = false;
         int rc = d->n_dyn ? KPGNN_OK : agg_narrow_fwd(d, (hipStream_t)stream, &handled);
         if (rc != KPGNN_OK || handled) return rc;
@@ -753,7 +755,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     p.x = d->x; p.x_sn = d->x_sn; p.x_sk = d->x_sk;
     p.table0 = d->table0; p.tablek = d->tablek;
     p.periph = d->periph; p.p_sn = d->p_sn; p.p_sk = d->p_sk;
-    p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.hinit = d->hinit; p.xbias = d->xbias;
+    p.eps = d->eps; p.out = d->out; p.o_sn = d->o_sn; p.o_sk = d->o_sk; p.pre = d->pre; p.theta = d->theta; p.hout = d->hout; p.hinit = d->hinit; p.hinit2 = d->hinit2; p.xbias = d->xbias;
     p.alphas = nullptr; p.theta_out = nullptr;
     if (d->alphas) {
         if (p.lds_theta) { p.alphas = d->alphas; p.theta_out = const_cast<float*>(d->theta); }   // theta staged in LDS: computed there
@@ -772,7 +774,7 @@ extern "C" int kpgnn_aggregate_fwd(const kpgnn_agg_fwd_desc* d, kpgnn_stream_t s
     const void* slot_align = (const void*)(slot_bits | 16);   // synthetic address carrying that alignment (never dereferenced)
     if ((uint64_t)d->N * (uint64_t)d->x_sn * 4u >= (1ull << 32))
         return fail(KPGNN_ELIMIT, "aggregate_fwd: N * x row stride = %lld floats exceeds the 32-bit byte offsets of the gather", (long long)d->N * d->x_sn);
-    const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->hinit, d->xbias, d->periph ? nullptr : d->ptab},
+    const int vec = pick_vec(d->D, {d->x ? (const void*)d->x : slot_align, d->periph, d->out, d->pre, d->table0, d->tablek, d->theta, d->hout, d->hinit, d->hinit2, d->xbias, d->periph ? nullptr : d->ptab},
                              {d->x_sn, d->x ? d->x_sk : 0, d->periph ? d->p_sn : 0, d->periph ? d->p_sk : 0,
                               d->out ? d->o_sn : 0, d->out ? d->o_sk : 0});
     const int lanes = (d->D + vec - 1) / vec;

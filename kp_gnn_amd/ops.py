@@ -315,7 +315,13 @@ PULL_GATHER = True      # (tests switch it off to compare with the read-modify-w
 _ones_cache = {}
 
 
-def khop_pull_gather(csr, slabs, hinit):
+def pull_applies(N, D, dtype=torch.float32):
+    """Whether KHopAggregate.backward takes the pull form for a [N, k, D] gradient of this dtype (the KP-GIN+ history pattern
+    is the caller's business): producers of other shares of a state's gradient use it to decide how to hand theirs over."""
+    return PULL_GATHER and dtype == torch.float32 and N >= 4096 and D % 4 == 0
+
+
+def khop_pull_gather(csr, slabs, hinit, hinit2=None):
     """A state's whole K-hop gradient in ONE launch (kpgnn_aggregate_fwd with the (source, hop)-keyed CSR, mode SUM, theta = 1
     and `hinit`): out[i] = hinit[i] + sum_k sum_{j in N_k(i)} slabs[k][j], where slabs[k] is hop k's [N,D] slab of dL/dS of the
     layer that read the state at hop slot k.  Replaces one read-modify-write of the state's gradient per reader (36 per step
@@ -338,7 +344,7 @@ def khop_pull_gather(csr, slabs, hinit):
     for k, t in enumerate(slabs):
         assert t.shape == (N, D) and t.is_contiguous() and t.dtype == torch.float32
         d.x_slot[k] = t.data_ptr()
-    d.theta, d.hout, d.hinit = ones.data_ptr(), out.data_ptr(), _ptr(hinit)
+    d.theta, d.hout, d.hinit, d.hinit2 = ones.data_ptr(), out.data_ptr(), _ptr(hinit), _ptr(hinit2)
     with torch.cuda.device(dev):
         if _timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -346,7 +352,8 @@ def khop_pull_gather(csr, slabs, hinit):
         _lib.check(lib.kpgnn_aggregate_fwd(ctypes.byref(d), _stream(out)), "kpgnn_aggregate_fwd (pull gather)")
         if _timer is not None:
             e1.record()
-            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 1, 0, extra_nd=1 + (hinit is not None)), e0, e1))
+            _timer.records.append(("agg_bwd", algorithmic_bytes(csr, K, D, 1, 0, extra_nd=1 + (hinit is not None) + (hinit2 is not None)),
+                                   e0, e1))
     return out
 
 
@@ -910,16 +917,26 @@ class KHopAggregate(torch.autograd.Function):
                     t = zeros
                 slabs.append(t)
             hb = c0.buf
-            hinit = hb if (hb is not None and hb.is_contiguous() and hb.dtype == torch.float32 and tuple(hb.shape) == tuple(slabs[0].shape)) else None
-            total = khop_pull_gather(csr, slabs[:16], hinit)
+            shape = tuple(slabs[0].shape)
+            ok = lambda t: t is not None and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == shape
+            hinit = hb if ok(hb) else None
+            ext = c0.take_addend()
+            hinit2 = ext if ok(ext) else None
+            total = khop_pull_gather(csr, slabs[:16], hinit, hinit2)
             if hb is not None and hinit is None:
                 total = total + hb.view_as(total)          # (odd layout: add the parked share the plain way)
+            if ext is not None and hinit2 is None:
+                total = total + ext.view_as(total)
             c0.buf = None
             return (None, gt0, gtk, gperiph, None, _finish_gtheta(ctx, gtheta, theta, galphas_done, k_act), None, gdict, None, None, None,
                     None, None, total, *([None] * (k_act - 1)))
         gx, a0, ak = aggregate_bwd_raw(csr, k_act, mode, g, eps, ctx.n_code0, ctx.n_codek, tables_in_gather,
                                        slots=ctx.n_slots > 0, slot_bufs=_slot_bufs(ctx), gx_accum=xbuf)
         if ctx.n_slots > 0 and ctx.cells is not None:
+            ext = ctx.cells[0].take_addend()      # (a share handed over for the pull form that this layer could not run)
+            if ext is not None:
+                gx = list(gx)
+                gx[0] = gx[0] + ext.view_as(gx[0])
             pend = ctx.cells[0].take_slabs()      # (later layers ran the pull form, this one could not: their slabs for ITS slot-0 state)
             if pend:
                 zeros = torch.zeros_like(next(iter(pend.values())))
@@ -978,11 +995,21 @@ class _SlotGradCell:
     no reader of ITS pass ever collects; the parked buffer is therefore tagged with the pass that wrote it
     (torch._C._current_graph_task_id()) and reads from any other pass see an empty cell - a stale share is never added to
     a later pass's gradient (tests/test_gpu_parity.py::test_gradient_cells_survive_a_partial_backward)."""
-    __slots__ = ("_buf", "_task", "_pend", "_ptask")
+    __slots__ = ("_buf", "_task", "_pend", "_ptask", "_add", "_atask")
 
     def __init__(self):
         self._buf, self._task = None, -1
         self._pend, self._ptask = None, -1
+        self._add, self._atask = None, -1       # one more [N,D] addend of the pull gather (the residual branch's share)
+
+    def park_addend(self, t):
+        self._add, self._atask = t, _backward_pass_id()
+
+    def take_addend(self):
+        t = self._add if self._atask == _backward_pass_id() else None
+        self._add, self._atask = None, -1
+        return t
+
 
     # Pull form of the backward gather (khop_pull_gather): a later reader of the state does not add its share into `buf` -
     # it leaves the hop slab of ITS dL/dS here, keyed by the hop slot it read the state at, and the state's last reader

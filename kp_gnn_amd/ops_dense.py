@@ -405,9 +405,17 @@ class FusedMLP(torch.autograd.Function):
         d.gamma, d.beta, d.mean, d.invstd = g2.data_ptr(), be2.data_ptr(), st[2].data_ptr(), st[3].data_ptr()
         d.stat_slot, d.reduce_only = slot2.data_ptr(), 1
         rbuf = None
+        handed = False
         if ctx.outer:
-            # the residual branch: a state whose gradient is collected in a cell gets += dz from the reduce pass itself
-            rbuf = ctx.res_cell.buf if (ctx.res_cell is not None and ctx.needs_input_grad[14]) else None
+            from . import ops
+            # the residual branch: d/dresidual is dz itself.  A state whose gradient is collected in a cell gets it either as one
+            # more addend of its pull gather (no pass at all) or += from the reduce pass below
+            want_res = ctx.res_cell is not None and ctx.needs_input_grad[14]
+            if want_res and ops.pull_applies(N, O):
+                ctx.res_cell.park_addend(dz)
+                handed = True
+            elif want_res:
+                rbuf = ctx.res_cell.buf
             d.outer_mean, d.outer_invstd = st[4].data_ptr(), st[5].data_ptr()
             if rbuf is not None:
                 d.residual_grad, d.rg_stride = rbuf.data_ptr(), rbuf.stride(0)
@@ -450,7 +458,7 @@ class FusedMLP(torch.autograd.Function):
                     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                     q.workspace, q.workspace_bytes = ws.data_ptr(), nb
                     _lib.check(lib.kpgnn_linear_wgrad(ctypes.byref(q), _stream(h)), "kpgnn_linear_wgrad")
-        gres = dz if (ctx.outer and ctx.has_res and rbuf is None) else None
+        gres = dz if (ctx.outer and ctx.has_res and rbuf is None and not handed) else None
         return (dh if ctx.needs_input_grad[0] else None, dw0, db[1] if ctx.has_b0 else None, gb[2], gb[3],
                 dw3, db[0] if ctx.has_b3 else None, gb[0], gb[1], None, None, None,
                 gb[4] if ctx.outer else None, gb[5] if ctx.outer else None, gres, None)
