@@ -53,7 +53,12 @@ dict_grad_kernel(DgParams p) {
     const int cc = col_ok ? c : 0;
     float* acc = lds;
     float* ghs = lds + U * K * D;
-    for (int i = threadIdx.x; i < U * K * D; i += kThreadsDG) acc[i] = 0.f;
+    // (16-byte stores: with one float per store this fill was 40 % of the launch - 6,000 of 15,000 cycles, s_memtime per phase)
+    {
+        const int n4 = (U * K * D) & ~3;
+        for (int i = threadIdx.x * 4; i < n4; i += kThreadsDG * 4) *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = n4 + threadIdx.x; i < U * K * D; i += kThreadsDG) acc[i] = 0.f;
+    }
     const int per = (p.N + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * per, n1 = min(p.N, n0 + per);
     const int chunk_floats = kChunk * D;              // multiple of 4 (D even, kChunk 64)
@@ -101,44 +106,58 @@ dict_grad_kernel(DgParams p) {
     float ta = 0.f, tb = 0.f;                         // this wave's share of the block's total (rows j = w mod 8 of every chunk)
     if (use_dom) {
         // No staging and no barriers: a wave reads the few rows it needs (its eighth of the chunk for the total, the nodes whose
-        // id at its hop is not the designated one) straight from L2, eight loads in flight at a time.
-        __syncthreads();                               // the accumulator rows are zero
-        for (int node0 = n0; node0 < n1; node0 += kChunk) {
-            uidv = nuid;
-            nuid = load_uid(node0 + kChunk);
-            const int nn = min(kChunk, n1 - node0);
-            const float* gb = p.gh + (int64_t)node0 * D + cc;
-            float2 tv[kChunk / kWavesDG];
+        // id at its hop is not the designated one) straight from L2.  A block's ~185 nodes are ~3 chunks: the ids and the total's
+        // rows of up to FOUR chunks are requested before anything is used (unconditional, clamped; one round trip instead of one
+        // per chunk: 19 -> 14 us per launch), only the few non-designated rows of a chunk depend on its ids.
+        constexpr int NCH = 4, RPW = kChunk / kWavesDG;
+        const int nlast = n1 - 1;                      // (n0 < n1 whenever anything is loaded)
+        for (int base = n0; base < n1; base += NCH * kChunk) {
+            int uids[NCH];
+            float2 tvs[NCH][RPW];
 #pragma unroll
-            for (int q = 0; q < kChunk / kWavesDG; ++q) {
-                const int j = q * kWavesDG + w;
-                tv[q] = j < nn ? *reinterpret_cast<const float2*>(gb + (int64_t)j * D) : make_float2(0.f, 0.f);
-            }
-            unsigned long long todo = (w < K) ? __ballot(uidv >= 0 && uidv != domk) : 0ull;
-            while (todo) {
-                int js[8]; float2 v[8];
+            for (int ch = 0; ch < NCH; ++ch)
+                uids[ch] = p.uid[(int64_t)min(base + ch * kChunk + lane, nlast) * p.uid_stride + (w < K ? w : 0)];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    js[q] = todo ? (int)__builtin_ctzll(todo) : -1;
-                    if (todo) todo &= todo - 1;
-                    v[q] = js[q] >= 0 ? *reinterpret_cast<const float2*>(gb + (int64_t)js[q] * D) : make_float2(0.f, 0.f);
-                }
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (js[q] >= 0) {
-                        const int u = __builtin_amdgcn_readlane(uidv, js[q]);
-                        if (u != cur) {                        // wave-uniform
-                            if (cur >= 0) leave();
-                            cur = u;
-                            ra = rb = 0.f;
+                for (int q = 0; q < RPW; ++q)
+                    tvs[ch][q] = *reinterpret_cast<const float2*>(p.gh + (int64_t)min(base + ch * kChunk + q * kWavesDG + w, nlast) * D + cc);
+            if (base == n0) __syncthreads();           // the accumulator rows are zero (their stores went out under the requests)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int node0 = base + ch * kChunk;
+                if (node0 >= n1) break;                // (uniform)
+                const int nn = min(kChunk, n1 - node0);
+                uidv = (w < K && lane < nn) ? uids[ch] : -1;
+                const float* gb = p.gh + (int64_t)node0 * D + cc;
+                unsigned long long todo = (w < K) ? __ballot(uidv >= 0 && uidv != domk) : 0ull;
+                while (todo) {
+                    int js[8]; float2 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        js[q] = todo ? (int)__builtin_ctzll(todo) : -1;
+                        if (todo) todo &= todo - 1;
+                        v[q] = js[q] >= 0 ? *reinterpret_cast<const float2*>(gb + (int64_t)js[q] * D) : make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (js[q] >= 0) {
+                            const int u = __builtin_amdgcn_readlane(uidv, js[q]);
+                            if (u != cur) {                        // wave-uniform
+                                if (cur >= 0) leave();
+                                cur = u;
+                                ra = rb = 0.f;
+                            }
+                            ra += v[q].x; rb += v[q].y;
                         }
-                        ra += v[q].x; rb += v[q].y;
                     }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < kChunk / kWavesDG; ++q) { ta += tv[q].x; tb += tv[q].y; }
+                for (int q = 0; q < RPW; ++q)
+                    if (q * kWavesDG + w < nn) { ta += tvs[ch][q].x; tb += tvs[ch][q].y; }
+            }
         }
+        if (n0 >= n1) __syncthreads();                 // (a block without nodes still meets the barrier count)
     }
     int buf = 0;
     for (int node0 = use_dom ? n1 : n0; node0 < n1; node0 += kChunk, buf ^= 1) {
@@ -198,17 +217,35 @@ dict_grad_kernel(DgParams p) {
             const int k = i / D, d = i - k * D;
             int dk = p.dom[k];
             if (dk < 0 || dk >= U) dk = 0;
-            float rest = 0.f;
-            for (int u = 0; u < U; ++u) if (u != dk) rest += acc[(u * K + k) * D + d];
-            acc[(dk * K + k) * D + d] = tot[kWavesDG * D + d] - rest;
+            // (four interleaved partial sums, ids u = j mod 4 each, added in a fixed order: the reads of one chain of U dependent
+            //  adds were 4,100 cycles)
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* col = acc + k * D + d;
+            int u = 0;
+            for (; u + 3 < U; u += 4) {
+                const float a0 = col[(u + 0) * K * D], a1 = col[(u + 1) * K * D], a2 = col[(u + 2) * K * D], a3 = col[(u + 3) * K * D];
+                r4[0] += (u + 0 != dk) ? a0 : 0.f; r4[1] += (u + 1 != dk) ? a1 : 0.f;
+                r4[2] += (u + 2 != dk) ? a2 : 0.f; r4[3] += (u + 3 != dk) ? a3 : 0.f;
+            }
+            for (; u < U; ++u) r4[u & 3] += (u != dk) ? col[u * K * D] : 0.f;
+            acc[(dk * K + k) * D + d] = tot[kWavesDG * D + d] - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
         }
         __syncthreads();
     }
-    // gdict_block[u, d] = sum_k theta[k, d] * acc[u, k, d], hops in order
+    // gdict_block[u, d] = sum_k theta[k, d] * acc[u, k, d], hops in order.  theta goes to LDS once (a global read per term made
+    // every term of the K-chain a round trip: 4,200 cycles), all K terms of an output are read before the chain starts.
+    float* th = ghs;                                  // [K][D]  (the staging buffers are free; K D <= 2 kChunk D)
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * D; i += kThreadsDG) th[i] = p.theta[i];
+    __syncthreads();
     for (int i = threadIdx.x; i < U * D; i += kThreadsDG) {
         const int u = i / D, d = i - u * D;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = k < K ? acc[(u * K + k) * D + d] * th[k * D + d] : 0.f;
         float s = 0.f;
-        for (int k = 0; k < K; ++k) s = fmaf(p.theta[k * D + d], acc[(u * K + k) * D + d], s);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < K) s += a[k];
         p.slab[(int64_t)blockIdx.x * U * D + i] = s;
     }
 }
