@@ -137,6 +137,7 @@ lin3_kernel(const L3Params p) {
                 if (MODE == 1) mk[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(mp) + off);
             }
         };
+        const bool tail = lim < ROWS - 1;                 // (uniform: only the batch's last block has rows to zero)
         auto commit = [&](int t, float4 (&v)[PF], float4 (&mk)[PF]) {
             if (t >= T) return;                           // (uniform; no request inside)
             __bf16* buf = pl + (t & (NB - 1)) * BUF;
@@ -144,7 +145,7 @@ lin3_kernel(const L3Params p) {
             for (int i = 0; i < PF; ++i) {
                 float4 x = v[i];
                 if (masked) { x.x = mk[i].x > 0.f ? x.x : 0.f; x.y = mk[i].y > 0.f ? x.y : 0.f; x.z = mk[i].z > 0.f ? x.z : 0.f; x.w = mk[i].w > 0.f ? x.w : 0.f; }
-                if (prow[i] > lim) x = make_float4(0.f, 0.f, 0.f, 0.f);               // (rows beyond N stay zero)
+                if (tail && prow[i] > lim) x = make_float4(0.f, 0.f, 0.f, 0.f);       // (rows beyond N stay zero)
                 bf3_u2 h0, m0, l0, h1, m1, l1;
                 bf3_split2(bf3_f2{x.x, x.y}, h0, m0, l0);
                 bf3_split2(bf3_f2{x.z, x.w}, h1, m1, l1);
