@@ -524,6 +524,8 @@ def main():
                        "global_batch": args.batch * (1 if strong else world),
                        "nodes_per_batch": b0.num_nodes, "khop_edges_per_batch": int(b0.csr.E),
                        "active_pairs_per_batch": int(b0.csr.A),
+                       "dense_math": "fp32 operands and accumulation; products on the bf16 matrix cores from exact three-way bf16 "
+                                     "splits (KPGNN_MATH_AUTO, bf3.h) where N >= 4096, else the fp32 matrix instruction",
                        "parallelism": f"dp{world}" + (" (one global batch partitioned by active pairs; rank 0's shard sizes are the "
                                                        "nodes / pairs fields; pairs per rank, first batch: " + str(shard_pairs[0]) + ")"
                                                        if strong else ""),
