@@ -805,6 +805,41 @@ typedef struct kpgnn_attn_desc {
 int kpgnn_attn_fwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
 int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
 
+/* The same operator for K <= 8 and D % 4 == 0, D <= 128 with the input projection inside (no gin tensor, no library
+ * GEMM in the forward): a wave owns 32 nodes of one direction, takes the projection W_ih x_t and the recurrent
+ * product W_hh h_{t-1} transposed (gates x nodes) on the fp32 matrix instruction - the accumulator layout then IS
+ * "the four gates of four hidden units of my node" - and runs the recurrence / BPTT on its accumulators
+ * (csrc/attention.hip, "scan form").  Takes the nn.LSTM parameters as they are ([4K,D], [4K,K], [4K] per direction;
+ * index 0 = forward, 1 = reverse; reference layers/combine.py:17).
+ *   fwd: hsum, w, out as kpgnn_attn_fwd; acts in the kernel's own lane-contiguous layout; w_pad [64, D] = the two
+ *        W_ih with the hidden size padded to 8 (row dir*32 + gate*8 + unit, zero rows for unit >= K).
+ *   bwd: dx (direct part) and ds as kpgnn_attn_bwd; dgin [N*K, 64] and hprev [N*K, 16] in the padded layout
+ *        (column dir*32 + gate*8 + unit / dir*8 + unit, zeros in the padding): dx += dgin w_pad, and
+ *        dW_pad = dgin^T x, db_pad = sum dgin, dW_hh_pad = dgin^T hprev are then plain products whose rows / columns
+ *        of the padding are dropped. */
+typedef struct kpgnn_attn_scan_desc {
+    int32_t N, K, D;
+    const float* x; int64_t x_sn, x_sk;     /* device [N,K,D], 16-byte aligned, strides multiples of 4 */
+    const float* w_ih[2];                   /* device [4K,D] weight_ih_l0, weight_ih_l0_reverse */
+    const float* w_hh[2];                   /* device [4K,K] */
+    const float* b_ih[2];                   /* device [4K] */
+    const float* b_hh[2];                   /* device [4K] */
+    float* acts;                            /* device [ceil(N/32)*2*K*20*64] (fwd: out, bwd: in) */
+    float* hsum;                            /* device [2,N,K] workspace */
+    float* w;                               /* device [N,K] softmax weights (fwd: out, bwd: in) */
+    float* out;                             /* device [N,D] (fwd) */
+    float* w_pad;                           /* device [64,D] (fwd: out) */
+    /* backward only */
+    const float* gout;                      /* device [N,D] */
+    float* dx;                              /* device [N,K,D] contiguous: the DIRECT part w[n,t]*gout[n,:] */
+    float* ds;                              /* device [N,K] workspace */
+    float* dgin;                            /* device [N*K,64] */
+    float* hprev;                           /* device [N*K,16] */
+} kpgnn_attn_scan_desc;
+
+int kpgnn_attn_scan_fwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream);
+int kpgnn_attn_scan_bwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream);
+
 /* Geometric hop-combine weights (reference layers/combine.py:43-50, GeometricCombine.geometric_distribution):
  *     a = sigmoid(alpha[d]);  theta[k,d] = softmax_k( a (1-a)^k )            theta: device [K,D], alpha: device [D]
  * and the backward  galpha[d] = d/dalpha sum_k gtheta[k,d] theta[k,d].  One launch each (the op-by-op version is

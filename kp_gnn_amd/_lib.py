@@ -173,6 +173,16 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
+class AttnScanDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("K", c_i32), ("D", c_i32),
+        ("x", c_vp), ("x_sn", c_i64), ("x_sk", c_i64),
+        ("w_ih", c_vp * 2), ("w_hh", c_vp * 2), ("b_ih", c_vp * 2), ("b_hh", c_vp * 2),
+        ("acts", c_vp), ("hsum", c_vp), ("w", c_vp), ("out", c_vp), ("w_pad", c_vp),
+        ("gout", c_vp), ("dx", c_vp), ("ds", c_vp), ("dgin", c_vp), ("hprev", c_vp),
+    ]
+
+
 class LinearDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i64), ("O", c_i32), ("I", c_i32),
@@ -311,6 +321,8 @@ SIGNATURES = {
     "kpgnn_stream_capture_id": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "kpgnn_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
+    "kpgnn_attn_scan_fwd": (ctypes.c_int, [ctypes.POINTER(AttnScanDesc), c_vp]),
+    "kpgnn_attn_scan_bwd": (ctypes.c_int, [ctypes.POINTER(AttnScanDesc), c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
     "kpgnn_linear_split_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
     "kpgnn_linear_split_many": (ctypes.c_int, [ctypes.POINTER(SplitJob), c_i32, c_vp]),

@@ -11,6 +11,7 @@ namespace kpgnn {
 namespace {
 
 constexpr int kBlock = 256;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 2.0f * sigm(2.0f * x) - 1.0f; }
@@ -177,6 +178,201 @@ __global__ void __launch_bounds__(kBlock) attn_lstm_bwd_kernel(const AtParams p)
 
 
 
+// ------------------------------------------------------------------------------------------------
+// The scan form (hidden size K <= 8, D % 4 == 0): input projection, recurrence and BPTT on the fp32 matrix
+// instruction, no gin tensor, no per-thread rows.
+//
+// A wave owns (32 nodes, one direction).  With the hidden size padded to 8 units the 4 x 8 = 32 gate rows of a
+// direction are ONE 32-row MFMA tile in the parameter's own order (i, f, g, o blocks of 8), and the products are
+// taken transposed - gates x nodes = W (32 x D) . x_t^T (D x 32) - so that lane l ends up with node l & 31 and,
+// in accumulator register r, gate r / 4 of unit 4 (l >> 5) + r % 4: the four gates of four units of its node, which
+// is what the recurrence needs.  Nothing is exchanged between lanes:
+//   * B operand of the input product = 4 consecutive floats of the lane's node row, straight from global memory
+//     (the contraction index of v_mfma_f32_32x32x2_f32 is the lane half, so lane (node, half) feeds columns
+//     8c + 4 half + i of chunk c in its i-th instruction); A = the weight row of gate l & 31, same columns, resident.
+//   * the recurrent product W_hh h_{t-1} is 4 more instructions on the same accumulators: the B operand of the
+//     i-th one is the lane's OWN h of unit 4 half + i.
+//   * BPTT's dh_{t-1} = W_hh^T dg is 16 instructions whose B operands are the lane's own 16 dg values; rows 0..7
+//     of the result land in accumulator registers 0..3 as the lane's own four units.
+// Padded units (>= K) have zero weights and biases: c = h = 0 for them, and their dg is masked.  The activations
+// saved for BPTT are written lane-contiguous ([tile][dir][t][20][64], 256 B per store instruction); dgin / hprev
+// leave in the padded layout [N*K, 64] / [N*K, 16] (16-B stores) that the weight-gradient and dX products read.
+struct ScanParams {
+    int N, K, D;
+    const float* x; int64_t x_sn, x_sk;
+    const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
+    float* acts; float* hsum; float* w_pad;
+    const float* ds; float* dgin; float* hprev;
+};
+
+constexpr int kScanThreads = 256;                    // 2 node tiles x 2 directions
+
+template <int CH>                                     // CH >= ceil(D / 8) chunks of 8 columns
+__global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dir = wv & 1;
+    const int tile = blockIdx.x * 2 + (wv >> 1);
+    const int ntiles = (p.N + 31) >> 5;
+    if (tile >= ntiles) return;                       // whole wave; no barriers in this kernel
+    const int K = p.K, D = p.D;
+    const int half = lane >> 5;
+    const int g = lane & 31, gtype = g >> 3, gunit = g & 7;
+    const bool grow_ok = gunit < K;
+    const int grow = gtype * K + (grow_ok ? gunit : 0);
+    const float* wih_p = p.w_ih[dir] + (int64_t)grow * D;
+    const float* whh_p = p.w_hh[dir] + grow * K;
+    float wih[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = 8 * c + 4 * half + i;
+            wih[c][i] = (grow_ok && col < D) ? wih_p[col] : 0.f;
+        }
+    float whh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * half + i;
+        whh[i] = (grow_ok && r < K) ? whh_p[r] : 0.f;
+    }
+    f32x16 bias;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int unit = 4 * half + (j & 3), row = (j >> 2) * K + unit;
+        bias[j] = unit < K ? p.b_ih[dir][row] + p.b_hh[dir][row] : 0.f;
+    }
+    if (blockIdx.x == 0 && wv < 2) {                  // the padded weight matrix the backward's dX product reads
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 8 * c + 4 * half + i;
+                if (col < D) p.w_pad[(int64_t)(dir * 32 + g) * D + col] = wih[c][i];
+            }
+    }
+    const int node = lane & 31;
+    const int64_t n = min((int64_t)tile * 32 + node, (int64_t)p.N - 1);
+    const bool n_ok = (int64_t)tile * 32 + node < p.N;
+    const float* xrow = p.x + n * p.x_sn + 4 * half;
+    // columns of the last chunk that do not exist are read from a clamped address; their weights are zero
+    int coff[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) coff[c] = 8 * c + 4 * half < D ? 8 * c : 0;
+    float4 xv[CH];
+    {
+        const float* xr = xrow + (int64_t)(dir ? K - 1 : 0) * p.x_sk;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+    }
+    float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f};
+    float* ap = p.acts + ((int64_t)(tile * 2 + dir) * K) * (20 * 64) + lane;
+    float* hs_p = p.hsum + ((int64_t)dir * p.N + n) * K;
+    for (int s = 0; s < K; ++s) {
+        const int t = dir ? K - 1 - s : s;
+        f32x16 acc = bias;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][0], xv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][1], xv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][2], xv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][3], xv[c].w, acc, 0, 0, 0);
+        }
+        {                                              // the next slot's columns are in flight during the recurrence
+            const int sn = s + 1 < K ? s + 1 : s;
+            const float* xr = xrow + (int64_t)(dir ? K - 1 - sn : sn) * p.x_sk;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(whh[i], hst[i], acc, 0, 0, 0);
+        float* a = ap + (int64_t)t * (20 * 64);
+        float hs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = sigm(acc[u]), fg = sigm(acc[4 + u]), gg = tanh_(acc[8 + u]), og = sigm(acc[12 + u]);
+            cst[u] = fmaf(fg, cst[u], ig * gg);
+            hst[u] = og * tanh_(cst[u]);
+            hs += hst[u];
+            a[u * 64] = ig; a[(4 + u) * 64] = fg; a[(8 + u) * 64] = gg; a[(12 + u) * 64] = og; a[(16 + u) * 64] = cst[u];
+        }
+        hs += __shfl_xor(hs, 32);
+        if (half == 0 && n_ok) hs_p[t] = hs;
+    }
+}
+
+__global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dir = wv & 1;
+    const int tile = blockIdx.x * 2 + (wv >> 1);
+    const int ntiles = (p.N + 31) >> 5;
+    if (tile >= ntiles) return;
+    const int K = p.K;
+    const int half = lane >> 5, m = lane & 31, node = lane & 31;
+    float wt[16];                                     // A operand of dh_{t-1} = W_hh^T dg: W_hh[gate(j, half)][m]
+    float live[4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int unit = 4 * half + (j & 3), row = (j >> 2) * K + unit;
+        wt[j] = (unit < K && m < K) ? p.w_hh[dir][row * K + m] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) live[u] = 4 * half + u < K ? 1.f : 0.f;
+    const int64_t nraw = (int64_t)tile * 32 + node;
+    const bool n_ok = nraw < p.N;
+    const int64_t n = min(nraw, (int64_t)p.N - 1);
+    const float* ap = p.acts + ((int64_t)(tile * 2 + dir) * K) * (20 * 64) + lane;
+    const float* ds_p = p.ds + n * K;
+    float cur[20], prv[20];
+    {
+        const float* a = ap + (int64_t)(dir ? 0 : K - 1) * (20 * 64);
+#pragma unroll
+        for (int q = 0; q < 20; ++q) cur[q] = a[q * 64];
+    }
+    float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = K - 1; s >= 0; --s) {
+        const int t = dir ? K - 1 - s : s;
+        const int tp = s > 0 ? (dir ? t + 1 : t - 1) : t;
+        {
+            const float* a = ap + (int64_t)tp * (20 * 64);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) prv[q] = a[q * 64];
+        }
+        const float dst = ds_p[t];
+        const float first = s > 0 ? 1.f : 0.f;        // the first visited slot starts from h = c = 0
+        float dg[16], hp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = cur[u], fg = cur[4 + u], gg = cur[8 + u], og = cur[12 + u], ct = cur[16 + u];
+            const float cp = first * prv[16 + u];
+            hp[u] = first * prv[12 + u] * tanh_(cp);
+            const float tc = tanh_(ct);
+            const float dhq = dh[u] + dst;
+            const float dcq = fmaf(dhq * og, 1.0f - tc * tc, dc[u]) * live[u];
+            dg[u] = dcq * gg * ig * (1.0f - ig);
+            dg[4 + u] = dcq * cp * fg * (1.0f - fg);
+            dg[8 + u] = dcq * ig * (1.0f - gg * gg);
+            dg[12 + u] = dhq * tc * og * (1.0f - og) * live[u];
+            dc[u] = dcq * fg;
+        }
+        if (n_ok) {
+            float* dgo = p.dgin + (n * K + t) * 64 + dir * 32 + 4 * half;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty)
+                *reinterpret_cast<float4*>(dgo + ty * 8) = make_float4(dg[4 * ty], dg[4 * ty + 1], dg[4 * ty + 2], dg[4 * ty + 3]);
+            *reinterpret_cast<float4*>(p.hprev + (n * K + t) * 16 + dir * 8 + 4 * half) = make_float4(hp[0], hp[1], hp[2], hp[3]);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[j], dg[j], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dh[u] = acc[u];
+#pragma unroll
+        for (int q = 0; q < 20; ++q) cur[q] = prv[q];
+    }
+}
+
 #define KP_K_SWITCH(KERNEL, GRID, BLOCK, S, P)                                                                   \
     switch (K) {                                                                                                 \
         case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, 0, S, P); break;                                      \
@@ -226,6 +422,67 @@ void fill(const kpgnn_attn_desc* d, AtParams* p) {
     p->dgin = d->dgin; p->hprev = d->hprev;
 }
 
+int launch_apply_fwd(const kpgnn_attn_desc* d, const AtParams& p, hipStream_t s) {
+    const int K = d->K;
+    dim3 blk(kBlock);
+    const int vec = apply_vec(d);
+    const int g = apply_group(d->D, vec);
+    if (g > 64) return fail(KPGNN_ELIMIT, "attention combine: D=%d needs more than 64 lanes", d->D);
+    int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
+    const int64_t cap = (int64_t)device_facts().cu_count * 8;
+    if (nb > cap) nb = cap;
+#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
+    switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
+#undef KP_AP
+    KPGNN_LAUNCH_CHECK("attn_apply_fwd_kernel");
+    return KPGNN_OK;
+}
+
+int launch_apply_bwd(const kpgnn_attn_desc* d, const AtParams& p, hipStream_t s) {
+    const int K = d->K;
+    dim3 blk(kBlock);
+    const int vec = apply_vec(d);
+    const int g = apply_group(d->D, vec);
+    if (g > 64) return fail(KPGNN_ELIMIT, "attention combine: D=%d needs more than 64 lanes", d->D);
+    int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
+    const int64_t cap = (int64_t)device_facts().cu_count * 8;
+    if (nb > cap) nb = cap;
+#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
+    switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
+#undef KP_AP
+    KPGNN_LAUNCH_CHECK("attn_apply_bwd_kernel");
+    return KPGNN_OK;
+}
+
+int check_scan(const kpgnn_attn_scan_desc* d, bool bwd) {
+    KPGNN_REQUIRE(d != nullptr, "attn_scan: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 0 && d->K >= 1 && d->D >= 1, "attn_scan: bad N=%d K=%d D=%d", d->N, d->K, d->D);
+    if (d->K > 8) return fail(KPGNN_ELIMIT, "attention scan: K=%d > 8 (use kpgnn_attn_fwd / _bwd)", d->K);
+    if (d->D > 128 || d->D % 4 != 0) return fail(KPGNN_ELIMIT, "attention scan: D=%d unsupported (a multiple of 4, <= 128)", d->D);
+    KPGNN_REQUIRE(d->x && d->acts && d->hsum && d->w, "attn_scan: NULL pointer");
+    KPGNN_REQUIRE((((uintptr_t)d->x) & 15) == 0 && d->x_sn % 4 == 0 && d->x_sk % 4 == 0, "attn_scan: x must be 16-byte aligned with strides that are multiples of 4");
+    for (int q = 0; q < 2; ++q) KPGNN_REQUIRE(d->w_ih[q] && d->w_hh[q] && d->b_ih[q] && d->b_hh[q], "attn_scan: NULL parameter pointer");
+    if (bwd) {
+        KPGNN_REQUIRE(d->gout && d->dx && d->ds && d->dgin && d->hprev, "attn_scan_bwd: NULL pointer");
+        KPGNN_REQUIRE((((uintptr_t)d->dgin) & 15) == 0 && (((uintptr_t)d->hprev) & 15) == 0, "attn_scan_bwd: dgin / hprev must be 16-byte aligned");
+    } else {
+        KPGNN_REQUIRE(d->out && d->w_pad, "attn_scan_fwd: NULL out / w_pad");
+    }
+    return KPGNN_OK;
+}
+
+void fill_scan(const kpgnn_attn_scan_desc* d, ScanParams* q, AtParams* p, kpgnn_attn_desc* a) {
+    q->N = d->N; q->K = d->K; q->D = d->D; q->x = d->x; q->x_sn = d->x_sn; q->x_sk = d->x_sk;
+    for (int i = 0; i < 2; ++i) { q->w_ih[i] = d->w_ih[i]; q->w_hh[i] = d->w_hh[i]; q->b_ih[i] = d->b_ih[i]; q->b_hh[i] = d->b_hh[i]; }
+    q->acts = d->acts; q->hsum = d->hsum; q->w_pad = d->w_pad; q->ds = d->ds; q->dgin = d->dgin; q->hprev = d->hprev;
+    *a = kpgnn_attn_desc{};
+    a->N = d->N; a->K = d->K; a->D = d->D; a->x = d->x; a->x_sn = d->x_sn; a->x_sk = d->x_sk;
+    a->hsum = d->hsum; a->w = d->w; a->out = d->out; a->gout = d->gout; a->dx = d->dx; a->ds = d->ds;
+    fill(a, p);
+}
+
 }  // namespace
 }  // namespace kpgnn
 
@@ -241,18 +498,7 @@ extern "C" int kpgnn_attn_fwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream) {
     dim3 grid((unsigned)((d->N + kBlock - 1) / kBlock), 2), blk(kBlock);
     KP_K_SWITCH(attn_lstm_fwd_kernel, grid, blk, s, p)
     KPGNN_LAUNCH_CHECK("attn_lstm_fwd_kernel");
-    const int vec = apply_vec(d);
-    const int g = apply_group(d->D, vec);
-    if (g > 64) return fail(KPGNN_ELIMIT, "attention combine: D=%d needs more than 64 lanes", d->D);
-    int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
-    const int64_t cap = (int64_t)device_facts().cu_count * 8;
-    if (nb > cap) nb = cap;
-#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
-                       else hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
-    switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
-#undef KP_AP
-    KPGNN_LAUNCH_CHECK("attn_apply_fwd_kernel");
-    return KPGNN_OK;
+    return launch_apply_fwd(d, p, s);
 }
 
 extern "C" int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream) {
@@ -263,19 +509,44 @@ extern "C" int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const int K = d->K;
     dim3 blk(kBlock);
-    const int vec = apply_vec(d);
-    const int g = apply_group(d->D, vec);
-    if (g > 64) return fail(KPGNN_ELIMIT, "attention combine: D=%d needs more than 64 lanes", d->D);
-    int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
-    const int64_t cap = (int64_t)device_facts().cu_count * 8;
-    if (nb > cap) nb = cap;
-#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
-                       else hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
-    switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
-#undef KP_AP
-    KPGNN_LAUNCH_CHECK("attn_apply_bwd_kernel");
+    rc = launch_apply_bwd(d, p, s);
+    if (rc != KPGNN_OK) return rc;
     dim3 grid((unsigned)((d->N + kBlock - 1) / kBlock), 2);
     KP_K_SWITCH(attn_lstm_bwd_kernel, grid, blk, s, p)
     KPGNN_LAUNCH_CHECK("attn_lstm_bwd_kernel");
+    return KPGNN_OK;
+}
+
+extern "C" int kpgnn_attn_scan_fwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream) {
+    int rc = check_scan(d, false);
+    if (rc != KPGNN_OK) return rc;
+    if (d->N == 0) return KPGNN_OK;
+    ScanParams q; AtParams p; kpgnn_attn_desc a;
+    fill_scan(d, &q, &p, &a);
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = (d->N + 31) / 32;
+    dim3 grid((unsigned)((ntiles + 1) / 2)), blk(kScanThreads);
+    const int ch = (d->D + 7) / 8;
+    if (ch <= 4) hipLaunchKernelGGL(attn_scan_fwd_kernel<4>, grid, blk, 0, s, q);
+    else if (ch <= 8) hipLaunchKernelGGL(attn_scan_fwd_kernel<8>, grid, blk, 0, s, q);
+    else if (ch <= 13) hipLaunchKernelGGL(attn_scan_fwd_kernel<13>, grid, blk, 0, s, q);
+    else hipLaunchKernelGGL(attn_scan_fwd_kernel<16>, grid, blk, 0, s, q);
+    KPGNN_LAUNCH_CHECK("attn_scan_fwd_kernel");
+    return launch_apply_fwd(&a, p, s);
+}
+
+extern "C" int kpgnn_attn_scan_bwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream) {
+    int rc = check_scan(d, true);
+    if (rc != KPGNN_OK) return rc;
+    if (d->N == 0) return KPGNN_OK;
+    ScanParams q; AtParams p; kpgnn_attn_desc a;
+    fill_scan(d, &q, &p, &a);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_apply_bwd(&a, p, s);
+    if (rc != KPGNN_OK) return rc;
+    const int ntiles = (d->N + 31) / 32;
+    dim3 grid((unsigned)((ntiles + 1) / 2)), blk(kScanThreads);
+    hipLaunchKernelGGL(attn_scan_bwd_kernel, grid, blk, 0, s, q);
+    KPGNN_LAUNCH_CHECK("attn_scan_bwd_kernel");
     return KPGNN_OK;
 }

@@ -90,9 +90,84 @@ class AttentionCombineFn(torch.autograd.Function):
                 dw_cat[4 * K:], dwhh_r, db_cat[4 * K:], db_cat[4 * K:])
 
 
+SCAN = True            # the scan form of the operator (input projection inside, K <= 8) where it applies
+SCAN_MIN_N = 1024      # below this the launch-count difference is all there is
+
+
+def scan_applies(x, K, D):
+    return (SCAN and x.is_cuda and x.dtype == torch.float32 and K <= 8 and D % 4 == 0 and D <= 128 and x.shape[0] >= SCAN_MIN_N
+            and x.stride(2) == 1 and x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def _scan_desc(x, params, acts, hsum, w):
+    N, K, D = x.shape
+    d = _lib.AttnScanDesc()
+    d.N, d.K, d.D = N, K, D
+    d.x, d.x_sn, d.x_sk = x.data_ptr(), x.stride(0), x.stride(1)
+    for q in range(2):
+        d.w_ih[q], d.w_hh[q], d.b_ih[q], d.b_hh[q] = (t.data_ptr() for t in params[4 * q:4 * q + 4])
+    d.acts, d.hsum, d.w = acts.data_ptr(), hsum.data_ptr(), w.data_ptr()
+    return d
+
+
+class AttentionScanFn(torch.autograd.Function):
+    """kpgnn_attn_scan_fwd / _bwd: projection + recurrence + BPTT on the matrix cores, wave = (32 nodes, direction)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        N, K, D = x.shape
+        dev = x.device
+        params = [t.contiguous() for t in params]
+        acts = torch.empty((((N + 31) // 32) * 2 * K * 20 * 64,), dtype=torch.float32, device=dev)
+        hsum = torch.empty((2, N, K), dtype=torch.float32, device=dev)
+        w = torch.empty((N, K), dtype=torch.float32, device=dev)
+        out = torch.empty((N, D), dtype=torch.float32, device=dev)
+        w_pad = torch.empty((64, D), dtype=torch.float32, device=dev)
+        d = _scan_desc(x, params, acts, hsum, w)
+        d.out, d.w_pad = out.data_ptr(), w_pad.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_attn_scan_fwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_fwd")
+        ctx.save_for_backward(x, acts, w, w_pad, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, acts, w, w_pad, *params = ctx.saved_tensors
+        lib = _lib.load()
+        gout = gout.contiguous()
+        N, K, D = x.shape
+        dev = x.device
+        dx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
+        ds = torch.empty((N, K), dtype=torch.float32, device=dev)
+        dgin = torch.empty((N * K, 64), dtype=torch.float32, device=dev)
+        hprev = torch.empty((N * K, 16), dtype=torch.float32, device=dev)
+        hsum = torch.empty((1,), dtype=torch.float32, device=dev)       # unused in backward
+        d = _scan_desc(x, params, acts, hsum, w)
+        d.gout, d.dx, d.ds, d.dgin, d.hprev = gout.data_ptr(), dx.data_ptr(), ds.data_ptr(), dgin.data_ptr(), hprev.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_attn_scan_bwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_bwd")
+        dx.view(N * K, D).addmm_(dgin, w_pad)
+        xf = x.reshape(N * K, D)
+        dw_pad, db_pad = _wgrad(dgin, xf, True)                          # [64, D], [64]
+        dwhh_pad, _ = _wgrad(dgin, hprev, False)                         # [64, 16]
+        dw = dw_pad.view(2, 4, 8, D)[:, :, :K].reshape(2, 4 * K, D)      # drop the padded units (views when K == 8)
+        db = db_pad.view(2, 4, 8)[:, :, :K].reshape(2, 4 * K)
+        hh = dwhh_pad.view(2, 4, 8, 2, 8)
+        dwhh_f = hh[0, :, :K, 0, :K].reshape(4 * K, K)
+        dwhh_r = hh[1, :, :K, 1, :K].reshape(4 * K, K)
+        return dx, dw[0], dwhh_f, db[0], db[0], dw[1], dwhh_r, db[1], db[1]
+
+
 def attention_combine(x, lstm):
     """x [N,K,D] -> [N,D] with the parameters of the reference's nn.LSTM(D, K, bidirectional=True)."""
     N, K, D = x.shape
+    if x.is_cuda and lstm.hidden_size == K:
+        xs = _last_contig(x.float())
+        if scan_applies(xs, K, D):
+            return AttentionScanFn.apply(xs, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                                         lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,
+                                         lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
     if x.is_cuda and K <= 16 and lstm.hidden_size == K and (D % 4 == 0 and D <= 256 or D <= 64):
         return AttentionCombineFn.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                                         lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,

@@ -864,6 +864,51 @@ def test_attention_combine_hip_vs_reference_goldens(golden_dir):
     assert n >= 4
 
 
+@pytest.mark.parametrize("N,K,D", [(3000, 8, 104), (2050, 5, 40), (1500, 2, 24), (1100, 3, 104), (4097, 7, 64), (1024, 8, 128)])
+def test_attention_scan_form_vs_float64_lstm_and_thread_form(N, K, D):
+    """The scan form of AttentionCombine (projection + recurrence + BPTT on the matrix instruction, K <= 8) against
+    torch's nn.LSTM evaluated in float64 on the CPU (reference layers/combine.py:22-27 with the same parameters), and
+    against the thread-per-node form of the same operator (which the reference goldens pin at small N)."""
+    import kp_gnn_amd.ops_combine as oc
+    from kp_gnn_amd.layers import AttentionCombine
+    dev = _dev()
+    torch.manual_seed(100 + K)
+    m = AttentionCombine(D, K)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.mul_(2.0)                              # gates away from the linear range
+    x0 = torch.randn(N, K, D)
+    ow = torch.randn(N, D)
+
+    ref = torch.nn.LSTM(D, K, 1, batch_first=True, bidirectional=True).double()
+    ref.load_state_dict({k.replace("attention_lstm.", ""): v.double() for k, v in m.state_dict().items()})
+    xr = x0.double().requires_grad_(True)
+    sc, _ = ref(xr)
+    outr = (xr * torch.softmax(sc.sum(-1), dim=1).unsqueeze(-1)).sum(1)
+    (outr * ow.double()).sum().backward()
+
+    def run(scan):
+        old = oc.SCAN
+        oc.SCAN = scan
+        try:
+            mm = AttentionCombine(D, K)
+            mm.load_state_dict(m.state_dict())
+            mm = mm.to(dev)
+            x = x0.to(dev).requires_grad_(True)
+            out = mm(x)
+            (out * ow.to(dev)).sum().backward()
+            return out.detach(), x.grad, {k: v.grad for k, v in mm.attention_lstm.named_parameters()}
+        finally:
+            oc.SCAN = old
+
+    assert oc.scan_applies(x0.to(dev), K, D)
+    for name, (out, gx, gp) in (("scan", run(True)), ("thread", run(False))):
+        _close(out, outr.float(), f"{name}:out", rtol=2e-4, atol=2e-5)
+        _close(gx, xr.grad.float(), f"{name}:grad_x", rtol=2e-4, atol=2e-5)
+        for k, g in gp.items():
+            _close(g, dict(ref.named_parameters())[k].grad.float(), f"{name}:grad[{k}]", rtol=5e-4, atol=5e-5)
+
+
 def test_per_hop_slot_inputs_equal_stacked_input():
     """KPGINPlusConv.forward_slots (k separate [N,H] states) == forward(stack): outputs and every gradient."""
     from kp_gnn_amd.layers import KPGINPlusConv
