@@ -813,10 +813,11 @@ int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
  * index 0 = forward, 1 = reverse; reference layers/combine.py:17).
  *   fwd: hsum, w, out as kpgnn_attn_fwd; acts in the kernel's own lane-contiguous layout; w_pad [64, D] = the two
  *        W_ih with the hidden size padded to 8 (row dir*32 + gate*8 + unit, zero rows for unit >= K).
- *   bwd: dx (direct part) and ds as kpgnn_attn_bwd; dgin [N*K, 64] and hprev [N*K, 16] in the padded layout
- *        (column dir*32 + gate*8 + unit / dir*8 + unit, zeros in the padding): dx += dgin w_pad, and
- *        dW_pad = dgin^T x, db_pad = sum dgin, dW_hh_pad = dgin^T hprev are then plain products whose rows / columns
- *        of the padding are dropped. */
+ *   bwd: ds as kpgnn_attn_bwd; dgin [N*K, 64] and hprev [N*K, 16] in the padded layout (column dir*32 + gate*8 + unit /
+ *        dir*8 + unit, zeros in the padding); then the COMPLETE dx[n,t,:] = w[n,t] gout[n,:] + dgin[(n,t),:] w_pad in one
+ *        launch (w_pad from the forward).  dW_pad = dgin^T x, db_pad = sum dgin, dW_hh_pad = dgin^T hprev are plain
+ *        weight-gradient products (kpgnn_linear_wgrad); kpgnn_attn_scan_unpad drops the padding:
+ *        dw [2,4K,D], db [2,4K], dwhh [2,4K,K] from dw_pad [64,D], db_pad [64], dwhh_pad [64,16]. */
 typedef struct kpgnn_attn_scan_desc {
     int32_t N, K, D;
     const float* x; int64_t x_sn, x_sk;     /* device [N,K,D], 16-byte aligned, strides multiples of 4 */
@@ -828,10 +829,10 @@ typedef struct kpgnn_attn_scan_desc {
     float* hsum;                            /* device [2,N,K] workspace */
     float* w;                               /* device [N,K] softmax weights (fwd: out, bwd: in) */
     float* out;                             /* device [N,D] (fwd) */
-    float* w_pad;                           /* device [64,D] (fwd: out) */
+    float* w_pad;                           /* device [64,D] (fwd: out, bwd: in) */
     /* backward only */
     const float* gout;                      /* device [N,D] */
-    float* dx;                              /* device [N,K,D] contiguous: the DIRECT part w[n,t]*gout[n,:] */
+    float* dx;                              /* device [N,K,D] contiguous, complete */
     float* ds;                              /* device [N,K] workspace */
     float* dgin;                            /* device [N*K,64] */
     float* hprev;                           /* device [N*K,16] */
@@ -839,6 +840,8 @@ typedef struct kpgnn_attn_scan_desc {
 
 int kpgnn_attn_scan_fwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream);
 int kpgnn_attn_scan_bwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream);
+int kpgnn_attn_scan_unpad(const float* dw_pad, const float* db_pad, const float* dwhh_pad, float* dw, float* db, float* dwhh,
+                          int32_t K, int32_t D, kpgnn_stream_t stream);
 
 /* Geometric hop-combine weights (reference layers/combine.py:43-50, GeometricCombine.geometric_distribution):
  *     a = sigmoid(alpha[d]);  theta[k,d] = softmax_k( a (1-a)^k )            theta: device [K,D], alpha: device [D]

@@ -323,6 +323,7 @@ SIGNATURES = {
     "kpgnn_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnDesc), c_vp]),
     "kpgnn_attn_scan_fwd": (ctypes.c_int, [ctypes.POINTER(AttnScanDesc), c_vp]),
     "kpgnn_attn_scan_bwd": (ctypes.c_int, [ctypes.POINTER(AttnScanDesc), c_vp]),
+    "kpgnn_attn_scan_unpad": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "kpgnn_linear_fwd": (ctypes.c_int, [ctypes.POINTER(LinearDesc), c_vp]),
     "kpgnn_linear_split_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
     "kpgnn_linear_split_many": (ctypes.c_int, [ctypes.POINTER(SplitJob), c_i32, c_vp]),

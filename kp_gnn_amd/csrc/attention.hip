@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(kBlock) attn_apply_bwd_kernel(const AtParams p
                 float v[VEC], d1[VEC];
                 ldv<VEC>(p.x + n * p.x_sn + (int64_t)t * p.x_sk + c0, v);
                 for (int q = 0; q < VEC; ++q) { part = fmaf(go[q], v[q], part); d1[q] = wt[t & 15] * go[q]; }
-                stv<VEC>(p.dx + (n * K + t) * (int64_t)p.D + c0, d1);
+                if (p.dx) stv<VEC>(p.dx + (n * K + t) * (int64_t)p.D + c0, d1);    // (the scan form adds it in its dX product)
             }
             for (int off = G / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);   // stays inside the sub-group
             dw[t & 15] = part;
@@ -252,7 +252,6 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
     }
     const int node = lane & 31;
     const int64_t n = min((int64_t)tile * 32 + node, (int64_t)p.N - 1);
-    const bool n_ok = (int64_t)tile * 32 + node < p.N;
     const float* xrow = p.x + n * p.x_sn + 4 * half;
     // columns of the last chunk that do not exist are read from a clamped address; their weights are zero
     int coff[CH];
@@ -267,21 +266,23 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
     float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f};
     float* ap = p.acts + ((int64_t)(tile * 2 + dir) * K) * (20 * 64) + lane;
     float* hs_p = p.hsum + ((int64_t)dir * p.N + n) * K;
-    for (int s = 0; s < K; ++s) {
+    // The first step is peeled: the waits of a loop header are the merge of its two entries, and entered straight
+    // from the prologue (no stores in flight) the merge drains the 21 stores of every step before the next one starts.
+    auto step = [&](const int s) {
         const int t = dir ? K - 1 - s : s;
         f32x16 acc = bias;
+        // each chunk's registers are reloaded with the next slot's columns right behind the four instructions that
+        // read them, in consumption order (the memory counter is in order: the header then waits for chunk 0 only)
+        const int sn = s + 1 < K ? s + 1 : s;
+        const float* xr = xrow + (int64_t)(dir ? K - 1 - sn : sn) * p.x_sk;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][0], xv[c].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][1], xv[c].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][2], xv[c].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][3], xv[c].w, acc, 0, 0, 0);
-        }
-        {                                              // the next slot's columns are in flight during the recurrence
-            const int sn = s + 1 < K ? s + 1 : s;
-            const float* xr = xrow + (int64_t)(dir ? K - 1 - sn : sn) * p.x_sk;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+            xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(whh[i], hst[i], acc, 0, 0, 0);
@@ -296,17 +297,21 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
             a[u * 64] = ig; a[(4 + u) * 64] = fg; a[(8 + u) * 64] = gg; a[(12 + u) * 64] = og; a[(16 + u) * 64] = cst[u];
         }
         hs += __shfl_xor(hs, 32);
-        if (half == 0 && n_ok) hs_p[t] = hs;
-    }
+        hs_p[t] = hs;       // unconditional (a store under a branch makes every wait in the loop a full drain): both halves hold the
+                            // same sum, and lanes past N recompute node N-1 bit for bit, so the duplicates write what is there
+    };
+    step(0);
+    for (int s = 1; s < K; ++s) step(s);
 }
 
+template <int K>                                      // slots = hidden size (2..8): the walk is unrolled, the three
+                                                      // activation buffers rotate by name and every wait is exact
 __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dir = wv & 1;
     const int tile = blockIdx.x * 2 + (wv >> 1);
     const int ntiles = (p.N + 31) >> 5;
     if (tile >= ntiles) return;
-    const int K = p.K;
     const int half = lane >> 5, m = lane & 31, node = lane & 31;
     float wt[16];                                     // A operand of dh_{t-1} = W_hh^T dg: W_hh[gate(j, half)][m]
     float live[4];
@@ -317,34 +322,44 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) live[u] = 4 * half + u < K ? 1.f : 0.f;
-    const int64_t nraw = (int64_t)tile * 32 + node;
-    const bool n_ok = nraw < p.N;
-    const int64_t n = min(nraw, (int64_t)p.N - 1);
+    const int64_t n = min((int64_t)tile * 32 + node, (int64_t)p.N - 1);
     const float* ap = p.acts + ((int64_t)(tile * 2 + dir) * K) * (20 * 64) + lane;
     const float* ds_p = p.ds + n * K;
-    float cur[20], prv[20];
-    {
-        const float* a = ap + (int64_t)(dir ? 0 : K - 1) * (20 * 64);
+    // forward visiting order: dir 0 goes t = 0..K-1, dir 1 goes t = K-1..0; BPTT walks it backwards:
+    // slot of BPTT step s (s = K-1..0) is t(s) = dir ? K-1-s : s, its predecessor in the forward order is t(s-1).
+    auto slot = [&](int s) { return dir ? K - 1 - s : s; };
+    float buf[3][20];
+    float dsv[K];
 #pragma unroll
-        for (int q = 0; q < 20; ++q) cur[q] = a[q * 64];
+    for (int s = 0; s < K; ++s) dsv[s] = ds_p[slot(s)];
+    {
+        const float* a = ap + (int64_t)slot(K - 1) * (20 * 64);
+        const float* b = ap + (int64_t)slot(K > 1 ? K - 2 : 0) * (20 * 64);
+#pragma unroll
+        for (int q = 0; q < 20; ++q) buf[0][q] = a[q * 64];
+#pragma unroll
+        for (int q = 0; q < 20; ++q) buf[1][q] = b[q * 64];
     }
     float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = K - 1; s >= 0; --s) {
-        const int t = dir ? K - 1 - s : s;
-        const int tp = s > 0 ? (dir ? t + 1 : t - 1) : t;
-        {
-            const float* a = ap + (int64_t)tp * (20 * 64);
 #pragma unroll
-            for (int q = 0; q < 20; ++q) prv[q] = a[q * 64];
+    for (int i = 0; i < K; ++i) {
+        const int s = K - 1 - i;
+        const int t = slot(s);
+        float (&cur)[20] = buf[i % 3];
+        float (&prv)[20] = buf[(i + 1) % 3];
+        float (&pp)[20] = buf[(i + 2) % 3];
+        if (s > 1) {                                   // two slots ahead: lands while this step computes
+            const float* a = ap + (int64_t)slot(s - 2) * (20 * 64);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) pp[q] = a[q * 64];
         }
-        const float dst = ds_p[t];
-        const float first = s > 0 ? 1.f : 0.f;        // the first visited slot starts from h = c = 0
+        const float dst = dsv[s];
         float dg[16], hp[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float ig = cur[u], fg = cur[4 + u], gg = cur[8 + u], og = cur[12 + u], ct = cur[16 + u];
-            const float cp = first * prv[16 + u];
-            hp[u] = first * prv[12 + u] * tanh_(cp);
+            const float cp = s > 0 ? prv[16 + u] : 0.f;                 // the first visited slot starts from h = c = 0
+            hp[u] = s > 0 ? prv[12 + u] * tanh_(cp) : 0.f;
             const float tc = tanh_(ct);
             const float dhq = dh[u] + dst;
             const float dcq = fmaf(dhq * og, 1.0f - tc * tc, dc[u]) * live[u];
@@ -354,22 +369,120 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
             dg[12 + u] = dhq * tc * og * (1.0f - og) * live[u];
             dc[u] = dcq * fg;
         }
-        if (n_ok) {
+        {   // unconditional: lanes past N recompute node N-1 bit for bit (the forward wrote them copies of its activations)
             float* dgo = p.dgin + (n * K + t) * 64 + dir * 32 + 4 * half;
 #pragma unroll
             for (int ty = 0; ty < 4; ++ty)
                 *reinterpret_cast<float4*>(dgo + ty * 8) = make_float4(dg[4 * ty], dg[4 * ty + 1], dg[4 * ty + 2], dg[4 * ty + 3]);
             *reinterpret_cast<float4*>(p.hprev + (n * K + t) * 16 + dir * 8 + 4 * half) = make_float4(hp[0], hp[1], hp[2], hp[3]);
         }
+        if (s > 0) {
+            f32x16 acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[j], dg[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dh[u] = acc[u];
+        }
+    }
+}
+
+// ---- dx[r, :] = w[r] gout[r / K, :] + dgin[r, 0:64] . w_pad[64, D]   (r = n K + t): the input-gradient product of
+// the scan form with the direct part of the weighted sum as its epilogue, so dx is written once.  Taken transposed
+// like the scan (d x rows = w_pad^T . dgin^T): wave dt owns output columns [32 dt, 32 dt + 32) with its 64 x 32 slice
+// of w_pad resident as the A operands; the 32 x 64 tile of dgin is one contiguous 8-KB block, staged through LDS
+// (double-buffered, one barrier per tile) and read as 16-byte B fragments by all four waves; a lane ends up with four
+// runs of 4 consecutive output columns of one row, stored as 16 bytes each.
+struct DxParams {
+    int64_t R; int K, D;
+    const float* dgin; const float* w_pad; const float* w; const float* gout; float* dx;
+};
+constexpr int kDxPitch = 68;                          // floats: 272-B rows, conflict-free 16-B fragment reads
+
+__global__ void __launch_bounds__(256) attn_dx_kernel(const DxParams p) {
+    __shared__ float4 tileb[2][32 * kDxPitch / 4];
+    const int lane = threadIdx.x & 63, dt = threadIdx.x >> 6;
+    const int half = lane >> 5, row = lane & 31;
+    const int D = p.D;
+    float a[8][4];
+    {
+        const int d = 32 * dt + row;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[c][i] = d < D ? p.w_pad[(int64_t)(8 * c + 4 * half + i) * D + d] : 0.f;
+    }
+    const int64_t ntiles = (p.R + 31) >> 5;
+    const int64_t last4 = p.R * 16 - 1;               // last 16-byte piece of dgin
+    const float4* src = reinterpret_cast<const float4*>(p.dgin);
+    float4 st0, st1;
+    int64_t tile = blockIdx.x;
+    auto fetch = [&](int64_t tl) {
+        const int64_t base = tl * 512 + threadIdx.x;
+        st0 = src[min(base, last4)];
+        st1 = src[min(base + 256, last4)];
+    };
+    auto park = [&](int b) {
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+        tileb[b][(i0 >> 4) * (kDxPitch / 4) + (i0 & 15)] = st0;
+        tileb[b][(i1 >> 4) * (kDxPitch / 4) + (i1 & 15)] = st1;
+    };
+    if (tile < ntiles) { fetch(tile); park(0); }
+    __syncthreads();
+    int b = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt);
         f32x16 acc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        const float4* tb = &tileb[b][row * (kDxPitch / 4) + half];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[j], dg[j], acc, 0, 0, 0);
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = tb[2 * c];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], v.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][2], v.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][3], v.w, acc, 0, 0, 0);
+        }
+        const int64_t r = tile * 32 + row;
+        if (r < p.R) {
+            const int64_t n = r / p.K;
+            const float wr = p.w[r];
+            const float* g = p.gout + n * D;
+            float* o = p.dx + r * D;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dh[u] = acc[u];
-#pragma unroll
-        for (int q = 0; q < 20; ++q) cur[q] = prv[q];
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * dt + 8 * q + 4 * half;
+                if (d < D) {
+                    const float4 gv = *reinterpret_cast<const float4*>(g + d);
+                    *reinterpret_cast<float4*>(o + d) = make_float4(fmaf(wr, gv.x, acc[4 * q]), fmaf(wr, gv.y, acc[4 * q + 1]),
+                                                                    fmaf(wr, gv.z, acc[4 * q + 2]), fmaf(wr, gv.w, acc[4 * q + 3]));
+                }
+            }
+        }
+        if (nxt < ntiles) park(b ^ 1);
+        __syncthreads();
+        b ^= 1;
+    }
+}
+
+// ---- the padded gradients back in the parameters' shapes, one launch: dw [2,4K,D], db [2,4K], dwhh [2,4K,K]
+__global__ void __launch_bounds__(256) attn_unpad_kernel(const float* dw_pad, const float* db_pad, const float* dwhh_pad,
+                                                         float* dw, float* db, float* dwhh, int K, int D) {
+    const int n_w = 2 * 4 * K * D, n_b = 2 * 4 * K, n_h = 2 * 4 * K * K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_w + n_b + n_h; i += gridDim.x * 256) {
+        if (i < n_w) {
+            const int d = i % D, row = i / D, dir = row / (4 * K), g = (row % (4 * K)) / K, u = row % K;
+            dw[i] = dw_pad[(int64_t)(dir * 32 + g * 8 + u) * D + d];
+        } else if (i < n_w + n_b) {
+            const int row = i - n_w, dir = row / (4 * K), g = (row % (4 * K)) / K, u = row % K;
+            db[row] = db_pad[dir * 32 + g * 8 + u];
+        } else {
+            const int j = i - n_w - n_b, c = j % K, row = j / K, dir = row / (4 * K), g = (row % (4 * K)) / K, u = row % K;
+            dwhh[j] = dwhh_pad[(dir * 32 + g * 8 + u) * 16 + dir * 8 + c];
+        }
     }
 }
 
@@ -466,7 +579,9 @@ int check_scan(const kpgnn_attn_scan_desc* d, bool bwd) {
     for (int q = 0; q < 2; ++q) KPGNN_REQUIRE(d->w_ih[q] && d->w_hh[q] && d->b_ih[q] && d->b_hh[q], "attn_scan: NULL parameter pointer");
     if (bwd) {
         KPGNN_REQUIRE(d->gout && d->dx && d->ds && d->dgin && d->hprev, "attn_scan_bwd: NULL pointer");
-        KPGNN_REQUIRE((((uintptr_t)d->dgin) & 15) == 0 && (((uintptr_t)d->hprev) & 15) == 0, "attn_scan_bwd: dgin / hprev must be 16-byte aligned");
+        KPGNN_REQUIRE(d->w_pad != nullptr, "attn_scan_bwd: NULL w_pad");
+        KPGNN_REQUIRE(((((uintptr_t)d->dgin) | ((uintptr_t)d->hprev) | ((uintptr_t)d->gout) | ((uintptr_t)d->dx)) & 15) == 0,
+                      "attn_scan_bwd: dgin / hprev / gout / dx must be 16-byte aligned");
     } else {
         KPGNN_REQUIRE(d->out && d->w_pad, "attn_scan_fwd: NULL out / w_pad");
     }
@@ -542,11 +657,40 @@ extern "C" int kpgnn_attn_scan_bwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t
     ScanParams q; AtParams p; kpgnn_attn_desc a;
     fill_scan(d, &q, &p, &a);
     hipStream_t s = (hipStream_t)stream;
+    p.dx = nullptr;                                    // ds only: the direct part of dx is the epilogue of attn_dx_kernel
     rc = launch_apply_bwd(&a, p, s);
     if (rc != KPGNN_OK) return rc;
     const int ntiles = (d->N + 31) / 32;
     dim3 grid((unsigned)((ntiles + 1) / 2)), blk(kScanThreads);
-    hipLaunchKernelGGL(attn_scan_bwd_kernel, grid, blk, 0, s, q);
+    switch (d->K) {
+        case 1: hipLaunchKernelGGL(attn_scan_bwd_kernel<1>, grid, blk, 0, s, q); break;
+        case 2: hipLaunchKernelGGL(attn_scan_bwd_kernel<2>, grid, blk, 0, s, q); break;
+        case 3: hipLaunchKernelGGL(attn_scan_bwd_kernel<3>, grid, blk, 0, s, q); break;
+        case 4: hipLaunchKernelGGL(attn_scan_bwd_kernel<4>, grid, blk, 0, s, q); break;
+        case 5: hipLaunchKernelGGL(attn_scan_bwd_kernel<5>, grid, blk, 0, s, q); break;
+        case 6: hipLaunchKernelGGL(attn_scan_bwd_kernel<6>, grid, blk, 0, s, q); break;
+        case 7: hipLaunchKernelGGL(attn_scan_bwd_kernel<7>, grid, blk, 0, s, q); break;
+        default: hipLaunchKernelGGL(attn_scan_bwd_kernel<8>, grid, blk, 0, s, q); break;
+    }
     KPGNN_LAUNCH_CHECK("attn_scan_bwd_kernel");
+    DxParams x;
+    x.R = (int64_t)d->N * d->K; x.K = d->K; x.D = d->D;
+    x.dgin = d->dgin; x.w_pad = d->w_pad; x.w = d->w; x.gout = d->gout; x.dx = d->dx;
+    const int64_t rtiles = (x.R + 31) / 32;
+    int64_t nb = (int64_t)device_facts().cu_count * 4;
+    if (nb > rtiles) nb = rtiles;
+    hipLaunchKernelGGL(attn_dx_kernel, dim3((unsigned)nb), dim3(256), 0, s, x);
+    KPGNN_LAUNCH_CHECK("attn_dx_kernel");
+    return KPGNN_OK;
+}
+
+extern "C" int kpgnn_attn_scan_unpad(const float* dw_pad, const float* db_pad, const float* dwhh_pad, float* dw, float* db,
+                                     float* dwhh, int32_t K, int32_t D, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(dw_pad && db_pad && dwhh_pad && dw && db && dwhh, "attn_scan_unpad: NULL pointer");
+    KPGNN_REQUIRE(K >= 1 && K <= 8 && D >= 1, "attn_scan_unpad: bad K=%d D=%d", K, D);
+    const int total = 8 * K * D + 8 * K + 8 * K * K;
+    hipLaunchKernelGGL(attn_unpad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dw_pad, db_pad, dwhh_pad, dw, db, dwhh, (int)K, (int)D);
+    KPGNN_LAUNCH_CHECK("attn_unpad_kernel");
     return KPGNN_OK;
 }

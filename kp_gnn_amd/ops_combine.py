@@ -144,19 +144,20 @@ class AttentionScanFn(torch.autograd.Function):
         hprev = torch.empty((N * K, 16), dtype=torch.float32, device=dev)
         hsum = torch.empty((1,), dtype=torch.float32, device=dev)       # unused in backward
         d = _scan_desc(x, params, acts, hsum, w)
+        d.w_pad = w_pad.data_ptr()
         d.gout, d.dx, d.ds, d.dgin, d.hprev = gout.data_ptr(), dx.data_ptr(), ds.data_ptr(), dgin.data_ptr(), hprev.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(lib.kpgnn_attn_scan_bwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_bwd")
-        dx.view(N * K, D).addmm_(dgin, w_pad)
+            _lib.check(lib.kpgnn_attn_scan_bwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_bwd")   # ds, dgin, hprev, dx
         xf = x.reshape(N * K, D)
         dw_pad, db_pad = _wgrad(dgin, xf, True)                          # [64, D], [64]
         dwhh_pad, _ = _wgrad(dgin, hprev, False)                         # [64, 16]
-        dw = dw_pad.view(2, 4, 8, D)[:, :, :K].reshape(2, 4 * K, D)      # drop the padded units (views when K == 8)
-        db = db_pad.view(2, 4, 8)[:, :, :K].reshape(2, 4 * K)
-        hh = dwhh_pad.view(2, 4, 8, 2, 8)
-        dwhh_f = hh[0, :, :K, 0, :K].reshape(4 * K, K)
-        dwhh_r = hh[1, :, :K, 1, :K].reshape(4 * K, K)
-        return dx, dw[0], dwhh_f, db[0], db[0], dw[1], dwhh_r, db[1], db[1]
+        dw = torch.empty((2, 4 * K, D), dtype=torch.float32, device=dev)
+        db = torch.empty((2, 4 * K), dtype=torch.float32, device=dev)
+        dwhh = torch.empty((2, 4 * K, K), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.kpgnn_attn_scan_unpad(dw_pad.data_ptr(), db_pad.data_ptr(), dwhh_pad.data_ptr(), dw.data_ptr(),
+                                                 db.data_ptr(), dwhh.data_ptr(), K, D, _stream(x)), "kpgnn_attn_scan_unpad")
+        return dx, dw[0], dwhh[0], db[0], db[0], dw[1], dwhh[1], db[1], db[1]
 
 
 def attention_combine(x, lstm):
