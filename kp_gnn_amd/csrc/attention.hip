@@ -5,6 +5,7 @@
 // owns one (node, direction); the 4K x K recurrent matrix is wave-uniform (scalar loads), h / c / the 4K gate
 // pre-activations live in registers (K is a template parameter).  The [N*K, D] x [D, 8K] input projection runs as
 // a library GEMM on the matrix cores before this kernel.
+#include "bf3.h"
 #include "kpgnn_common.h"
 
 namespace kpgnn {
@@ -187,9 +188,10 @@ __global__ void __launch_bounds__(kBlock) attn_lstm_bwd_kernel(const AtParams p)
 // taken transposed - gates x nodes = W (32 x D) . x_t^T (D x 32) - so that lane l ends up with node l & 31 and,
 // in accumulator register r, gate r / 4 of unit 4 (l >> 5) + r % 4: the four gates of four units of its node, which
 // is what the recurrence needs.  Nothing is exchanged between lanes:
-//   * B operand of the input product = 4 consecutive floats of the lane's node row, straight from global memory
-//     (the contraction index of v_mfma_f32_32x32x2_f32 is the lane half, so lane (node, half) feeds columns
-//     8c + 4 half + i of chunk c in its i-th instruction); A = the weight row of gate l & 31, same columns, resident.
+//   * B operand of the input product = 8 consecutive floats of the lane's node row, straight from global memory
+//     (lane (node, half) feeds columns 16 ks + 8 half + e of k-step ks), split in registers into three bf16 pieces;
+//     A = the weight row of gate l & 31, same columns, split once and resident; six products per k-step on
+//     v_mfma_f32_32x32x16_bf16 give the fp32 product (bf3.h).
 //   * the recurrent product W_hh h_{t-1} is 4 more instructions on the same accumulators: the B operand of the
 //     i-th one is the lane's OWN h of unit 4 half + i.
 //   * BPTT's dh_{t-1} = W_hh^T dg is 16 instructions whose B operands are the lane's own 16 dg values; rows 0..7
@@ -207,13 +209,12 @@ struct ScanParams {
 
 constexpr int kScanThreads = 256;                    // 2 node tiles x 2 directions
 
-template <int CH>                                     // CH >= ceil(D / 8) chunks of 8 columns
+template <int KS>                                     // KS >= ceil(D / 16) k-steps of the bf16 instruction
 __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dir = wv & 1;
     const int tile = blockIdx.x * 2 + (wv >> 1);
     const int ntiles = (p.N + 31) >> 5;
-    if (tile >= ntiles) return;                       // whole wave; no barriers in this kernel
     const int K = p.K, D = p.D;
     const int half = lane >> 5;
     const int g = lane & 31, gtype = g >> 3, gunit = g & 7;
@@ -221,14 +222,34 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
     const int grow = gtype * K + (grow_ok ? gunit : 0);
     const float* wih_p = p.w_ih[dir] + (int64_t)grow * D;
     const float* whh_p = p.w_hh[dir] + grow * K;
-    float wih[CH][4];
+    // The input projection runs on the bf16 instruction from exact three-way splits (bf3.h): the fp32 instruction made
+    // the launch matrix-bound at ~70 TFLOP/s.  A = the gate row's weights, columns 16 ks + 8 half + e: split once per
+    // block by the first wave of each direction and kept in LDS in fragment order (84 registers otherwise).
+    __shared__ uint4 wl[2][KS][3][64];
+    const bool pad_out = blockIdx.x == 0;              // block 0 also leaves the padded fp32 matrix for the backward
+    if (wv < 2) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int ks = 0; ks < KS; ++ks) {
+        uint32_t hw[4], mw[4], lw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = 8 * c + 4 * half + i;
-            wih[c][i] = (grow_ok && col < D) ? wih_p[col] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const int col = 16 * ks + 8 * half + 2 * e;
+            const bool ok = col < D;                   // (D is a multiple of 4: the pair is in or out together)
+            bf3_f2 v;
+            v.x = (grow_ok && ok) ? wih_p[col] : 0.f;
+            v.y = (grow_ok && ok) ? wih_p[col + 1] : 0.f;
+            if (pad_out && ok) { float* o = p.w_pad + (int64_t)(dir * 32 + g) * D + col; o[0] = v.x; o[1] = v.y; }
+            bf3_u2 h, m, l;
+            bf3_split2(v, h, m, l);
+            hw[e] = bf3_pack(h.x, h.y); mw[e] = bf3_pack(m.x, m.y); lw[e] = bf3_pack(l.x, l.y);
         }
+        wl[dir][ks][0][lane] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        wl[dir][ks][1][lane] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        wl[dir][ks][2][lane] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+    }
+    __syncthreads();
+    if (tile >= ntiles) return;                       // whole wave; no barriers below
     float whh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -241,27 +262,23 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
         const int unit = 4 * half + (j & 3), row = (j >> 2) * K + unit;
         bias[j] = unit < K ? p.b_ih[dir][row] + p.b_hh[dir][row] : 0.f;
     }
-    if (blockIdx.x == 0 && wv < 2) {                  // the padded weight matrix the backward's dX product reads
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = 8 * c + 4 * half + i;
-                if (col < D) p.w_pad[(int64_t)(dir * 32 + g) * D + col] = wih[c][i];
-            }
-    }
     const int node = lane & 31;
     const int64_t n = min((int64_t)tile * 32 + node, (int64_t)p.N - 1);
-    const float* xrow = p.x + n * p.x_sn + 4 * half;
-    // columns of the last chunk that do not exist are read from a clamped address; their weights are zero
-    int coff[CH];
+    const float* xrow = p.x + n * p.x_sn;
+    // 16-byte pieces past the row's end are read from column 0 instead; their weights are zero
+    int coff[KS][2];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) coff[c] = 8 * c + 4 * half < D ? 8 * c : 0;
-    float4 xv[CH];
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int col = 16 * ks + 8 * half + 4 * q; coff[ks][q] = col < D ? col : 0; }
+    float4 xv[KS][2];
     {
         const float* xr = xrow + (int64_t)(dir ? K - 1 : 0) * p.x_sk;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+        for (int ks = 0; ks < KS; ++ks) {
+            xv[ks][0] = *reinterpret_cast<const float4*>(xr + coff[ks][0]);
+            xv[ks][1] = *reinterpret_cast<const float4*>(xr + coff[ks][1]);
+        }
     }
     float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f};
     float* ap = p.acts + ((int64_t)(tile * 2 + dir) * K) * (20 * 64) + lane;
@@ -271,17 +288,30 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_fwd_kernel(const ScanP
     auto step = [&](const int s) {
         const int t = dir ? K - 1 - s : s;
         f32x16 acc = bias;
-        // each chunk's registers are reloaded with the next slot's columns right behind the four instructions that
-        // read them, in consumption order (the memory counter is in order: the header then waits for chunk 0 only)
+        // each k-step's registers are reloaded with the next slot's columns right behind the instructions that read
+        // them, in consumption order (the memory counter is in order: the header then waits for the first piece only)
         const int sn = s + 1 < K ? s + 1 : s;
         const float* xr = xrow + (int64_t)(dir ? K - 1 - sn : sn) * p.x_sk;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][0], xv[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][1], xv[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][2], xv[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wih[c][3], xv[c].w, acc, 0, 0, 0);
-            xv[c] = *reinterpret_cast<const float4*>(xr + coff[c]);
+        for (int ks = 0; ks < KS; ++ks) {
+            bf3_u2 h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            bf3_split2(bf3_f2{xv[ks][0].x, xv[ks][0].y}, h0, m0, l0);
+            bf3_split2(bf3_f2{xv[ks][0].z, xv[ks][0].w}, h1, m1, l1);
+            bf3_split2(bf3_f2{xv[ks][1].x, xv[ks][1].y}, h2, m2, l2);
+            bf3_split2(bf3_f2{xv[ks][1].z, xv[ks][1].w}, h3, m3, l3);
+            xv[ks][0] = *reinterpret_cast<const float4*>(xr + coff[ks][0]);
+            xv[ks][1] = *reinterpret_cast<const float4*>(xr + coff[ks][1]);
+            const bf3_x8 bh = __builtin_bit_cast(bf3_x8, make_uint4(bf3_pack(h0.x, h0.y), bf3_pack(h1.x, h1.y), bf3_pack(h2.x, h2.y), bf3_pack(h3.x, h3.y)));
+            const bf3_x8 bm = __builtin_bit_cast(bf3_x8, make_uint4(bf3_pack(m0.x, m0.y), bf3_pack(m1.x, m1.y), bf3_pack(m2.x, m2.y), bf3_pack(m3.x, m3.y)));
+            const bf3_x8 bl = __builtin_bit_cast(bf3_x8, make_uint4(bf3_pack(l0.x, l0.y), bf3_pack(l1.x, l1.y), bf3_pack(l2.x, l2.y), bf3_pack(l3.x, l3.y)));
+            const bf3_x8 ah = __builtin_bit_cast(bf3_x8, wl[dir][ks][0][lane]), am = __builtin_bit_cast(bf3_x8, wl[dir][ks][1][lane]),
+                         al = __builtin_bit_cast(bf3_x8, wl[dir][ks][2][lane]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);                  // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -393,25 +423,43 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
 // like the scan (d x rows = w_pad^T . dgin^T): wave dt owns output columns [32 dt, 32 dt + 32) with its 64 x 32 slice
 // of w_pad resident as the A operands; the 32 x 64 tile of dgin is one contiguous 8-KB block, staged through LDS
 // (double-buffered, one barrier per tile) and read as 16-byte B fragments by all four waves; a lane ends up with four
-// runs of 4 consecutive output columns of one row, stored as 16 bytes each.
+// runs of 4 consecutive output columns of one row, stored as 16 bytes each.  The products run on the bf16 matrix
+// instruction from exact three-way splits (bf3.h; the fp32 instruction made this launch matrix-bound at ~70 TFLOP/s):
+// w_pad is split once per wave, the tile once by the threads that stage it.
 struct DxParams {
     int64_t R; int K, D;
     const float* dgin; const float* w_pad; const float* w; const float* gout; float* dx;
 };
-constexpr int kDxPitch = 68;                          // floats: 272-B rows, conflict-free 16-B fragment reads
+constexpr int kDxPk = 144;                            // bytes per staged row of one piece plane: 64 bf16 + 16 (16-B fragment
+                                                      // reads of 16 consecutive rows land on distinct banks)
 
 __global__ void __launch_bounds__(256) attn_dx_kernel(const DxParams p) {
-    __shared__ float4 tileb[2][32 * kDxPitch / 4];
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][32 * kDxPk];
     const int lane = threadIdx.x & 63, dt = threadIdx.x >> 6;
     const int half = lane >> 5, row = lane & 31;
     const int D = p.D;
-    float a[8][4];
+    bf3_x8 wa[4][3];                                  // w_pad^T, split once: rows d = 32 dt + row, k = 16 ks + 8 half + e
     {
         const int d = 32 * dt + row;
+        const bool ok = d < D;
+        const float* wc = p.w_pad + (ok ? d : 0);
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int ks = 0; ks < 4; ++ks) {
+            uint32_t hw[4], mw[4], lw[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[c][i] = d < D ? p.w_pad[(int64_t)(8 * c + 4 * half + i) * D + d] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int k0 = 16 * ks + 8 * half + 2 * e;
+                bf3_f2 v;
+                v.x = ok ? wc[(int64_t)k0 * D] : 0.f;
+                v.y = ok ? wc[(int64_t)(k0 + 1) * D] : 0.f;
+                bf3_u2 h, m, l;
+                bf3_split2(v, h, m, l);
+                hw[e] = bf3_pack(h.x, h.y); mw[e] = bf3_pack(m.x, m.y); lw[e] = bf3_pack(l.x, l.y);
+            }
+            wa[ks][0] = __builtin_bit_cast(bf3_x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+            wa[ks][1] = __builtin_bit_cast(bf3_x8, make_uint4(mw[0], mw[1], mw[2], mw[3]));
+            wa[ks][2] = __builtin_bit_cast(bf3_x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+        }
     }
     const int64_t ntiles = (p.R + 31) >> 5;
     const int64_t last4 = p.R * 16 - 1;               // last 16-byte piece of dgin
@@ -423,11 +471,18 @@ __global__ void __launch_bounds__(256) attn_dx_kernel(const DxParams p) {
         st0 = src[min(base, last4)];
         st1 = src[min(base + 256, last4)];
     };
-    auto park = [&](int b) {
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
-        tileb[b][(i0 >> 4) * (kDxPitch / 4) + (i0 & 15)] = st0;
-        tileb[b][(i1 >> 4) * (kDxPitch / 4) + (i1 & 15)] = st1;
+    // the staging threads split: every element once, three bf16 planes in LDS (8-byte stores, 16 lanes = one row)
+    auto park1 = [&](int b, int idx, const float4 v) {
+        bf3_u2 h0, m0, l0, h1, m1, l1;
+        bf3_split2(bf3_f2{v.x, v.y}, h0, m0, l0);
+        bf3_split2(bf3_f2{v.z, v.w}, h1, m1, l1);
+        unsigned char* q = &planes[b][0][(idx >> 4) * kDxPk + (idx & 15) * 8];
+        *reinterpret_cast<uint2*>(q) = make_uint2(bf3_pack(h0.x, h0.y), bf3_pack(h1.x, h1.y));
+        *reinterpret_cast<uint2*>(q + 32 * kDxPk) = make_uint2(bf3_pack(m0.x, m0.y), bf3_pack(m1.x, m1.y));
+        *reinterpret_cast<uint2*>(q + 64 * kDxPk) = make_uint2(bf3_pack(l0.x, l0.y), bf3_pack(l1.x, l1.y));
     };
+    auto park = [&](int b) { park1(b, threadIdx.x, st0); park1(b, threadIdx.x + 256, st1); };
+    auto ld8 = [&](const unsigned char* q) { return __builtin_bit_cast(bf3_x8, *reinterpret_cast<const uint4*>(q)); };
     if (tile < ntiles) { fetch(tile); park(0); }
     __syncthreads();
     int b = 0;
@@ -437,14 +492,16 @@ __global__ void __launch_bounds__(256) attn_dx_kernel(const DxParams p) {
         f32x16 acc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        const float4* tb = &tileb[b][row * (kDxPitch / 4) + half];
+        const unsigned char* bp = &planes[b][0][row * kDxPk + 16 * half];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 v = tb[2 * c];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], v.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], v.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][2], v.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][3], v.w, acc, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf3_x8 bh = ld8(bp + 32 * ks), bm = ld8(bp + 32 * kDxPk + 32 * ks), bl = ld8(bp + 64 * kDxPk + 32 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][2], bh, acc, 0, 0, 0);          // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], bh, acc, 0, 0, 0);
         }
         const int64_t r = tile * 32 + row;
         if (r < p.R) {
@@ -641,11 +698,11 @@ extern "C" int kpgnn_attn_scan_fwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = (d->N + 31) / 32;
     dim3 grid((unsigned)((ntiles + 1) / 2)), blk(kScanThreads);
-    const int ch = (d->D + 7) / 8;
-    if (ch <= 4) hipLaunchKernelGGL(attn_scan_fwd_kernel<4>, grid, blk, 0, s, q);
-    else if (ch <= 8) hipLaunchKernelGGL(attn_scan_fwd_kernel<8>, grid, blk, 0, s, q);
-    else if (ch <= 13) hipLaunchKernelGGL(attn_scan_fwd_kernel<13>, grid, blk, 0, s, q);
-    else hipLaunchKernelGGL(attn_scan_fwd_kernel<16>, grid, blk, 0, s, q);
+    const int ks = (d->D + 15) / 16;
+    if (ks <= 2) hipLaunchKernelGGL(attn_scan_fwd_kernel<2>, grid, blk, 0, s, q);
+    else if (ks <= 4) hipLaunchKernelGGL(attn_scan_fwd_kernel<4>, grid, blk, 0, s, q);
+    else if (ks <= 7) hipLaunchKernelGGL(attn_scan_fwd_kernel<7>, grid, blk, 0, s, q);
+    else hipLaunchKernelGGL(attn_scan_fwd_kernel<8>, grid, blk, 0, s, q);
     KPGNN_LAUNCH_CHECK("attn_scan_fwd_kernel");
     return launch_apply_fwd(&a, p, s);
 }
