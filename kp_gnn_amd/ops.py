@@ -714,6 +714,8 @@ class KHopAggregate(torch.autograd.Function):
         # is a view of (or None): its other readers' gradients are then collected in one buffer (see khop_aggregate)
         ctx.cells = cells if xs else None
         ctx.x_cell = cells if (not xs and cells is not None) else None
+        if ctx.cells:       # (the unfused epilogue - attention combine - hands back a node-major [N,k,D] gradient: no pull form)
+            ctx.cells[0].pull_reader = bool(PULL_GATHER and mode == MODE_GINPLUS and theta is not None and eps is None)
         _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
         ctx.n_slots = len(xs)
         bf16 = False
@@ -995,12 +997,14 @@ class _SlotGradCell:
     no reader of ITS pass ever collects; the parked buffer is therefore tagged with the pass that wrote it
     (torch._C._current_graph_task_id()) and reads from any other pass see an empty cell - a stale share is never added to
     a later pass's gradient (tests/test_gpu_parity.py::test_gradient_cells_survive_a_partial_backward)."""
-    __slots__ = ("_buf", "_task", "_pend", "_ptask", "_add", "_atask")
+    __slots__ = ("_buf", "_task", "_pend", "_ptask", "_add", "_atask", "pull_reader")
 
     def __init__(self):
         self._buf, self._task = None, -1
         self._pend, self._ptask = None, -1
         self._add, self._atask = None, -1       # one more [N,D] addend of the pull gather (the residual branch's share)
+        self.pull_reader = False                # set in forward by the state's slot-0 reader when its backward will be the pull
+                                                # form (fused geometric combine): only then is an addend worth parking
 
     def park_addend(self, t):
         self._add, self._atask = t, _backward_pass_id()

@@ -411,7 +411,7 @@ class FusedMLP(torch.autograd.Function):
             # the residual branch: d/dresidual is dz itself.  A state whose gradient is collected in a cell gets it either as one
             # more addend of its pull gather (no pass at all) or += from the reduce pass below
             want_res = ctx.res_cell is not None and ctx.needs_input_grad[14]
-            if want_res and ops.pull_applies(N, O):
+            if want_res and ops.pull_applies(N, O) and ctx.res_cell.pull_reader:
                 ctx.res_cell.park_addend(dz)
                 handed = True
             elif want_res:
