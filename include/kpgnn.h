@@ -438,6 +438,28 @@ size_t kpgnn_dict_grad_workspace_bytes(int32_t N, int32_t K, int32_t D, int32_t 
 int32_t kpgnn_dict_grad_slabs(int32_t N);
 int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t stream);
 
+/* The same gradient for ALL the layers of a sequential stack that read one dictionary (models/GNNs.py:393-400: every layer
+ * adds the same peripheral rows), in one launch:
+ *   gdict[u,:] = sum_l sum_{k < K[l]} theta[l][k,:] * sum over nodes i with uid[i,k] == u of gh[l][i,:]
+ * A launch of kpgnn_dict_grad is mostly fixed-size passes over its [n_dict*K, D] accumulator table (one block per CU);
+ * here the table is filled once, each layer's rows enter it already multiplied by that layer's theta, and the
+ * designated-row fix and the final hop sum run once.  `dominant` (a designated id per hop, kpgnn_dict_grad_desc) is
+ * required; K[l] <= 8, L <= 16, LDS: (n_dict*Kmax + 9 L) * D * 4 bytes <= 160 KB.  workspace as kpgnn_dict_grad's for Kmax. */
+typedef struct kpgnn_dict_grad_multi_desc {
+    int32_t N, D, n_dict, L;
+    const int32_t* uid;         /* device [N, uid_stride] */
+    int64_t uid_stride;
+    const float* theta[16];     /* device [K[l], D] each */
+    const float* gh[16];        /* device [N, D] contiguous each */
+    int32_t K[16];
+    float* gdict;               /* device [n_dict, D] (overwritten) */
+    void* workspace;
+    size_t workspace_bytes;
+    const int32_t* dominant;    /* device [Kmax] */
+    const int32_t* n_dyn;       /* optional live-row count */
+} kpgnn_dict_grad_multi_desc;
+int kpgnn_dict_grad_multi(const kpgnn_dict_grad_multi_desc* d, kpgnn_stream_t stream);
+
 /* Backward pre-pass of the fused epilogue (elementwise, streaming):  with v = act(S) + P,
  *   gv[i,k,:] = theta[k,:] * gh[i,:]     (fused geometric combine)   or   gout[i,k,:]   (theta == NULL)
  *   g[i,k,:]  = gv * act'(S[i,k,:])                      act = gelu (GINPLUS) / relu (GCN) / identity

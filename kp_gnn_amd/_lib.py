@@ -81,6 +81,15 @@ class DictGradDesc(ctypes.Structure):
     ]
 
 
+class DictGradMultiDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("D", c_i32), ("n_dict", c_i32), ("L", c_i32),
+        ("uid", c_vp), ("uid_stride", c_i64),
+        ("theta", c_vp * 16), ("gh", c_vp * 16), ("K", c_i32 * 16),
+        ("gdict", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t), ("dominant", c_vp), ("n_dyn", c_vp),
+    ]
+
+
 class CombineBwdDesc(ctypes.Structure):
     _fields_ = [
         ("N", c_i32), ("K", c_i32), ("D", c_i32), ("mode", c_i32),
@@ -289,6 +298,7 @@ SIGNATURES = {
     "kpgnn_table_grad_fuse_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "kpgnn_dict_grad_workspace_bytes": (ctypes.c_size_t, [c_i32] * 4),
     "kpgnn_dict_grad": (ctypes.c_int, [ctypes.POINTER(DictGradDesc), c_vp]),
+    "kpgnn_dict_grad_multi": (ctypes.c_int, [ctypes.POINTER(DictGradMultiDesc), c_vp]),
     "kpgnn_dict_grad_slabs": (c_i32, [c_i32]),
     "kpgnn_tile_pack_filter": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "kpgnn_tile_pack_prefixes": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -250,6 +250,176 @@ dict_grad_kernel(DgParams p) {
     }
 }
 
+// ---- the same gradient for ALL the layers that read one dictionary, in one launch:
+//   gdict[u,:] = sum_l sum_{k < K_l} theta_l[k,:] * sum over nodes i with uid[i,k] == u of gh_l[i,:]
+// A launch of the kernel above is mostly its fixed passes - filling the [U K][D] accumulator table, the designated-row fix, the
+// final hop sum: ~14,000 of its 18,000 cycles, one block per CU - and a sequential stack runs it once per layer over the SAME
+// ids.  Here the table is filled once, every layer's rows are added into it already multiplied by that layer's theta (so the
+// final pass is a plain sum over hops), and the fix runs once with  T_k = sum_l theta_l[k] * (block total of gh_l).
+// Designated ids are required (the variant that reads the few non-designated rows straight from L2).
+constexpr int kMaxDgLayers = 16;
+struct DgMultiParams {
+    const int32_t* n_dyn;
+    int N, K, D, U, L;                      // K = the largest K_l
+    const int32_t* uid; int64_t uid_stride;
+    const float* theta[kMaxDgLayers]; const float* gh[kMaxDgLayers]; int Kl[kMaxDgLayers];
+    float* slab;                            // [gridDim.x][U][D]
+    const int32_t* dom;                     // [K]
+};
+
+// LDS (floats): acc [U*K][D] | tot [L][kWavesDG][D] | totl [L][D]
+__global__ void __launch_bounds__(kThreadsDG)
+dict_grad_multi_kernel(DgMultiParams p) {
+    p.N = live_rows(p.N, p.n_dyn);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int D = p.D, K = p.K, U = p.U, L = p.L;
+    const int c = lane * 2;
+    const bool col_ok = c < D;                        // D is even
+    const int cc = col_ok ? c : 0;
+    float* acc = lds;
+    float* tot = lds + U * K * D;
+    float* totl = tot + L * kWavesDG * D;
+    {
+        const int n4 = (U * K * D) & ~3;
+        for (int i = threadIdx.x * 4; i < n4; i += kThreadsDG * 4) *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = n4 + threadIdx.x; i < U * K * D; i += kThreadsDG) acc[i] = 0.f;
+    }
+    const int per = (p.N + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(p.N, n0 + per);
+    int cur = -1;
+    float ra = 0.f, rb = 0.f;
+    bool pending = false;
+    float* pq = acc;
+    float2 pold = make_float2(0.f, 0.f), psum = make_float2(0.f, 0.f);
+    auto settle = [&]() {
+        if (pending) { if (col_ok) *reinterpret_cast<float2*>(pq) = make_float2(pold.x + psum.x, pold.y + psum.y); pending = false; }
+    };
+    auto leave = [&]() {
+        settle();
+        pq = acc + (cur * K + w) * D + cc;
+        pold = *reinterpret_cast<const float2*>(pq);
+        psum = make_float2(ra, rb);
+        pending = true;
+    };
+    int domk = -2;
+    if (w < K) { domk = p.dom[w]; if (domk < 0 || domk >= U) domk = 0; }
+    // (Measured alternatives, both slower than this plain loop's 96 us for 8 layers: the first 8 non-designated rows of EVERY chunk
+    //  requested up front with the total's rows, unconditionally - 112 us, the clamped requests of the hops that have none cost
+    //  more than the trips they save; two chunks at a time with the next layer's requests in flight - 115 us.)
+    constexpr int NCH = 4, RPW = kChunk / kWavesDG;
+    const int nlast = n1 - 1;
+    bool zeroed = false;
+    for (int base = n0; base < n1; base += NCH * kChunk) {
+        int uids[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            uids[ch] = p.uid[(int64_t)min(base + ch * kChunk + lane, nlast) * p.uid_stride + (w < K ? w : 0)];
+        for (int l = 0; l < L; ++l) {
+            // (the layer's pointers are picked with uniform selects over constant indices: indexing the argument struct with a
+            //  runtime value copies it to scratch, and every use becomes a scratch load - 134 us instead of 96)
+            const float* gh = p.gh[0]; const float* thp = p.theta[0]; int kl = p.Kl[0];
+#pragma unroll
+            for (int q = 1; q < kMaxDgLayers; ++q) if (q == l) { gh = p.gh[q]; thp = p.theta[q]; kl = p.Kl[q]; }
+            const bool hop_on = w < kl;
+            float2 tvs[NCH][RPW];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int q = 0; q < RPW; ++q)
+                    tvs[ch][q] = *reinterpret_cast<const float2*>(gh + (int64_t)min(base + ch * kChunk + q * kWavesDG + w, nlast) * D + cc);
+            const float2 th = hop_on ? *reinterpret_cast<const float2*>(thp + w * D + cc) : make_float2(0.f, 0.f);
+            if (!zeroed) { __syncthreads(); zeroed = true; }   // the accumulator rows are zero (their stores went out under the requests)
+            float ta = 0.f, tb = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int node0 = base + ch * kChunk;
+                if (node0 >= n1) break;                // (uniform)
+                const int nn = min(kChunk, n1 - node0);
+                const int uidv = (hop_on && lane < nn) ? uids[ch] : -1;
+                const float* gb = gh + (int64_t)node0 * D + cc;
+                unsigned long long todo = hop_on ? __ballot(uidv >= 0 && uidv != domk) : 0ull;
+                while (todo) {
+                    int js[8]; float2 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        js[q] = todo ? (int)__builtin_ctzll(todo) : -1;
+                        if (todo) todo &= todo - 1;
+                        v[q] = js[q] >= 0 ? *reinterpret_cast<const float2*>(gb + (int64_t)js[q] * D) : make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (js[q] >= 0) {
+                            const int u = __builtin_amdgcn_readlane(uidv, js[q]);
+                            if (u != cur) {                        // wave-uniform
+                                if (cur >= 0) leave();
+                                cur = u;
+                                ra = rb = 0.f;
+                            }
+                            ra = fmaf(th.x, v[q].x, ra); rb = fmaf(th.y, v[q].y, rb);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RPW; ++q)
+                    if (q * kWavesDG + w < nn) { ta += tvs[ch][q].x; tb += tvs[ch][q].y; }
+            }
+            // this wave's share of the block's total of layer l (rows j = w mod 8 of every chunk); one writer per slot
+            float* ts = tot + (l * kWavesDG + w) * D + cc;
+            if (col_ok) {
+                if (base == n0) *reinterpret_cast<float2*>(ts) = make_float2(ta, tb);
+                else { const float2 o = *reinterpret_cast<const float2*>(ts); *reinterpret_cast<float2*>(ts) = make_float2(o.x + ta, o.y + tb); }
+            }
+        }
+    }
+    if (!zeroed) {                                     // a block without nodes: zero totals, and it still meets the barrier count
+        for (int i = threadIdx.x; i < L * kWavesDG * D; i += kThreadsDG) tot[i] = 0.f;
+        __syncthreads();
+    }
+    if (cur >= 0) leave();
+    settle();
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * D; i += kThreadsDG) {
+        const int l = i / D, d = i - l * D;
+        float t = 0.f;
+        for (int q = 0; q < kWavesDG; ++q) t += tot[(l * kWavesDG + q) * D + d];
+        totl[i] = t;
+    }
+    __syncthreads();
+    // the designated rows: acc[dom_k, k, :] = sum_l theta_l[k] * (block total of layer l) - (the hop's other ids)
+    for (int i = threadIdx.x; i < K * D; i += kThreadsDG) {
+        const int k = i / D, d = i - k * D;
+        int dk = p.dom[k];
+        if (dk < 0 || dk >= U) dk = 0;
+        float T = 0.f;
+#pragma unroll
+        for (int l = 0; l < kMaxDgLayers; ++l)
+            if (l < L) T += k < p.Kl[l] ? p.theta[l][k * D + d] * totl[l * D + d] : 0.f;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* col = acc + k * D + d;
+        int u = 0;
+        for (; u + 3 < U; u += 4) {
+            const float a0 = col[(u + 0) * K * D], a1 = col[(u + 1) * K * D], a2 = col[(u + 2) * K * D], a3 = col[(u + 3) * K * D];
+            r4[0] += (u + 0 != dk) ? a0 : 0.f; r4[1] += (u + 1 != dk) ? a1 : 0.f;
+            r4[2] += (u + 2 != dk) ? a2 : 0.f; r4[3] += (u + 3 != dk) ? a3 : 0.f;
+        }
+        for (; u < U; ++u) r4[u & 3] += (u != dk) ? col[u * K * D] : 0.f;
+        acc[(dk * K + k) * D + d] = T - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < U * D; i += kThreadsDG) {
+        const int u = i / D, d = i - u * D;
+        float a[kWavesDG];
+#pragma unroll
+        for (int k = 0; k < kWavesDG; ++k) a[k] = k < K ? acc[(u * K + k) * D + d] : 0.f;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWavesDG; ++k) if (k < K) s2 += a[k];
+        p.slab[(int64_t)blockIdx.x * U * D + i] = s2;
+    }
+}
+
 struct DgPlan { int grid; size_t lds, ws_bytes; };
 
 // has_dom: the launch carries a designated id per hop - that path reads gh straight from L2 and needs no staging buffers
@@ -306,5 +476,37 @@ extern "C" int kpgnn_dict_grad(const kpgnn_dict_grad_desc* d, kpgnn_stream_t str
     hipLaunchKernelGGL(dict_grad_kernel, dim3(pl.grid), dim3(kThreadsDG), pl.lds, s, p);
     KPGNN_LAUNCH_CHECK("dict_grad_kernel");
     if (d->defer_reduce) return KPGNN_OK;
+    return slab_reduce(p.slab, pl.grid, (int64_t)p.U * p.D, d->gdict, (int64_t)p.U * p.D, nullptr, 0, nullptr, s);
+}
+
+extern "C" int kpgnn_dict_grad_multi(const kpgnn_dict_grad_multi_desc* d, kpgnn_stream_t stream) {
+    KPGNN_REQUIRE(d != nullptr, "dict_grad_multi: NULL descriptor");
+    KPGNN_REQUIRE(d->N >= 1 && d->D >= 1 && d->n_dict >= 1 && d->L >= 1, "dict_grad_multi: bad N=%d D=%d n_dict=%d L=%d", d->N, d->D,
+                  d->n_dict, d->L);
+    if (d->L > kMaxDgLayers) return fail(KPGNN_ELIMIT, "dict_grad_multi: L=%d > %d layers", d->L, kMaxDgLayers);
+    KPGNN_REQUIRE(d->uid && d->dominant && d->gdict && d->workspace, "dict_grad_multi: NULL uid / dominant / gdict / workspace");
+    int K = 0;
+    for (int l = 0; l < d->L; ++l) {
+        KPGNN_REQUIRE(d->theta[l] && d->gh[l] && d->K[l] >= 1, "dict_grad_multi: layer %d: NULL theta / gh or K < 1", l);
+        if (d->K[l] > K) K = d->K[l];
+    }
+    KPGNN_REQUIRE(d->uid_stride >= K, "dict_grad_multi: uid_stride < K");
+    DgPlan pl;
+    if (!dg_plan(d->N, K, d->D, d->n_dict, &pl, true))
+        return fail(KPGNN_ELIMIT, "dict_grad_multi: K=%d (<= 8), even D=%d (<= 128) needed", K, d->D);
+    pl.lds = sizeof(float) * ((size_t)d->n_dict * K * d->D + (size_t)d->L * (kWavesDG + 1) * d->D);
+    if (pl.lds > 160 * 1024) return fail(KPGNN_ELIMIT, "dict_grad_multi: %zu bytes of LDS needed (n_dict=%d, L=%d)", pl.lds, d->n_dict, d->L);
+    KPGNN_REQUIRE(d->workspace_bytes >= pl.ws_bytes, "dict_grad_multi: workspace too small (%zu < %zu)", (size_t)d->workspace_bytes, pl.ws_bytes);
+    DgMultiParams p;
+    p.N = d->N; p.n_dyn = d->n_dyn; p.K = K; p.D = d->D; p.U = d->n_dict; p.L = d->L;
+    p.uid = d->uid; p.uid_stride = d->uid_stride; p.slab = (float*)d->workspace; p.dom = d->dominant;
+    for (int l = 0; l < kMaxDgLayers; ++l) {
+        p.theta[l] = l < d->L ? d->theta[l] : nullptr; p.gh[l] = l < d->L ? d->gh[l] : nullptr; p.Kl[l] = l < d->L ? d->K[l] : 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (pl.lds > 64 * 1024) KPGNN_HIP_TRY(ensure_dynamic_lds((const void*)dict_grad_multi_kernel, pl.lds));
+    hipLaunchKernelGGL(dict_grad_multi_kernel, dim3(pl.grid), dim3(kThreadsDG), pl.lds, s, p);
+    KPGNN_LAUNCH_CHECK("dict_grad_multi_kernel");
+    // gdict = (gdict_acc +) the slabs in block order
     return slab_reduce(p.slab, pl.grid, (int64_t)p.U * p.D, d->gdict, (int64_t)p.U * p.D, nullptr, 0, nullptr, s);
 }

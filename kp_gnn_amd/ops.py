@@ -493,6 +493,56 @@ def dict_grad_raw(uid, n_dict, theta, gh, defer=False):
     return gd
 
 
+DICT_MULTI = True      # one dictionary-gradient launch per backward pass instead of one per layer (where the layers qualify)
+
+
+def dict_multi_ok(uid, n_dict, theta, gh):
+    """Whether a layer's dictionary share can wait for the one launch of dict_grad_multi_raw."""
+    if not DICT_MULTI or uid is None or theta is None:
+        return False
+    N, K = uid.shape
+    D = gh.shape[1]
+    dom = getattr(uid, "_kp_dom", None)
+    return (dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == gh.device
+            and uid.stride(1) == 1 and uid.dtype == torch.int32 and K <= 8 and D % 2 == 0 and D <= 128 and gh.dtype == torch.float32
+            and theta.dtype == torch.float32 and tuple(theta.shape) == (K, D) and 4 * (n_dict * 8 + 9 * 16) * D <= 160 * 1024)
+
+
+def dict_grad_multi_raw(items, n_dict):
+    """kpgnn_dict_grad_multi over the parked (uid view, theta, gh) of the layers that read one dictionary:
+    gdict[u] = sum_l sum_k theta_l[k] * sum_{i: uid[i,k]==u} gh_l[i].  The uid views are hop prefixes of ONE id matrix."""
+    lib = _lib.load()
+    uid = max((it[0] for it in items), key=lambda u: u.shape[1])
+    N, K = uid.shape
+    D = items[0][2].shape[1]
+    dev = items[0][2].device
+    base = uid.data_ptr()
+    assert len(items) <= 16 and all(it[0].data_ptr() == base and it[0].stride(0) == uid.stride(0) and it[0].shape[0] == N for it in items)
+    keep = []
+    d = _lib.DictGradMultiDesc()
+    d.N, d.D, d.n_dict, d.L = N, D, n_dict, len(items)
+    d.uid, d.uid_stride = base, uid.stride(0)
+    for l, (u, th, gh) in enumerate(items):
+        th, gh = th.contiguous(), gh.contiguous()
+        keep += [th, gh]
+        d.theta[l], d.gh[l], d.K[l] = th.data_ptr(), gh.data_ptr(), u.shape[1]
+    d.dominant = uid._kp_dom.data_ptr()
+    d.n_dyn = dyn_ptr(N)
+    ws_bytes = int(lib.kpgnn_dict_grad_workspace_bytes(N, K, D, n_dict))
+    gd = torch.empty((n_dict, D), dtype=torch.float32, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d.gdict, d.workspace, d.workspace_bytes = gd.data_ptr(), ws.data_ptr(), ws_bytes
+    with torch.cuda.device(dev):
+        if _timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.kpgnn_dict_grad_multi(ctypes.byref(d), _stream(gd)), "kpgnn_dict_grad_multi")
+        if _timer is not None:
+            e1.record()
+            _timer.records.append(("dict_grad", len(items) * 4 * N * D + 4 * N * K + 4 * D * n_dict, e0, e1))
+    return gd
+
+
 def table_grad_raw(csr, g, n_code0, n_codek, edges=True, uid=None, n_dict=0, theta=None, gh=None, kernel=0, extra=None,
                    gdict_acc=None):
     """Launch kpgnn_table_grad on g = dL/dS [N,k,D]: edge-code table gradients (no per-edge atomics) and /
@@ -788,6 +838,7 @@ class KHopAggregate(torch.autograd.Function):
         want_gdict = ctx.n_dict > 0 and ctx.needs_input_grad[7]
         gtheta = gperiph = gdict = acc = None
         acc_used = False
+        dict_parked = False
         gout = gout.contiguous() if fused else _last_contig(gout)
         want_tables = ctx.has_tables and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gt0 = gtk = None
@@ -802,9 +853,14 @@ class KHopAggregate(torch.autograd.Function):
             if want_gdict and ctx.dict_cell is not None and ctx.dict_cell.buf is not None:
                 acc = ctx.dict_cell.buf                       # later layers' share: the finishing launch adds to it
             if want_gdict and pre.shape[0] >= 4096:
-                dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)
-                extra = dg
-            in_walk = ctx.n_dict if (want_gdict and dg is None) else 0   # small batches: the dictionary rows ride along
+                if ctx.dict_cell is not None and dict_multi_ok(uid, ctx.n_dict, theta, gout):
+                    ctx.dict_cell.park_dict(uid, theta, gout)        # ONE launch for all the layers, run by the last of them
+                    dict_parked = True
+                    acc = None
+                else:
+                    dg = dict_grad_raw(uid, ctx.n_dict, theta, gout, defer=True)
+                    extra = dg
+            in_walk = ctx.n_dict if (want_gdict and dg is None and not dict_parked) else 0   # small batches: the dictionary rows ride along
             r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
                                        want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas, extra=extra, dict_rows=in_walk,
                                        gdict_acc=acc)
@@ -812,6 +868,9 @@ class KHopAggregate(torch.autograd.Function):
                 r = combine_table_grad_raw(csr, pre, gout, theta, ptab, uid, ctx.n_code0, ctx.n_codek,
                                            want_gtheta=ctx.needs_input_grad[5], alphas=ctx.alphas)
                 in_walk = 0
+            if r is None and dict_parked:            # (no fused kernel for this shape after all: the share goes the plain way below)
+                ctx.dict_cell._dg.pop()
+                dict_parked = False
             if r is not None:
                 g, gtheta, gt0, gtk = r[:4]
                 if isinstance(gtheta, tuple):
@@ -823,7 +882,7 @@ class KHopAggregate(torch.autograd.Function):
                 elif in_walk:
                     gdict = r[4]
                     acc = None
-                elif want_gdict:
+                elif want_gdict and not dict_parked:
                     gdict = table_grad_raw(csr, g, 0, 0, edges=False, uid=uid, n_dict=ctx.n_dict, theta=theta, gh=gout)[2]
                 done = True
             elif dg is not None:
@@ -881,17 +940,25 @@ class KHopAggregate(torch.autograd.Function):
                     raise _lib.KpgnnError("peripheral dictionary too large for the LDS table-gradient kernel; "
                                           "pass a dense peripheral_attr instead")
                 gdict = r2[2]
+        if ctx.dict_cell is not None and want_gdict and ctx.dict_first:
+            items = ctx.dict_cell.take_dicts()       # the last reader in backward order: every parked layer's share in ONE launch
+            if items:
+                gm = dict_grad_multi_raw(items, ctx.n_dict)
+                gdict = gm if gdict is None else gdict + gm
         if ctx.dict_cell is not None and want_gdict:
-            if acc_used:
-                acc = None                           # (already inside gdict)
-            elif acc is None and not done and ctx.dict_cell.buf is not None:
-                acc = ctx.dict_cell.buf
-            if acc is not None:                      # (a path without the accumulating launch: add the parked share the plain way)
-                gdict = gdict + acc
-            if ctx.dict_first:
-                ctx.dict_cell.buf = None             # the total goes to autograd
+            if dict_parked and not ctx.dict_first:
+                gdict = None                         # (this layer's share waits in the cell's list; a share in `buf` stays where it is)
             else:
-                ctx.dict_cell.buf, gdict = gdict, None
+                if acc_used:
+                    acc = None                       # (already inside gdict)
+                elif acc is None and (not done or dict_parked) and ctx.dict_cell.buf is not None:
+                    acc = ctx.dict_cell.buf
+                if acc is not None:                  # (a path without the accumulating launch: add the parked share the plain way)
+                    gdict = gdict + acc
+                if ctx.dict_first:
+                    ctx.dict_cell.buf = None         # the total goes to autograd
+                else:
+                    ctx.dict_cell.buf, gdict = gdict, None
         xbuf = None
         if (ctx.x_cell is not None and ctx.x_cell.buf is not None and ctx.needs_input_grad[0] and k_act <= 32
                 and mode != MODE_GCN and not tables_in_gather):
@@ -997,7 +1064,7 @@ class _SlotGradCell:
     no reader of ITS pass ever collects; the parked buffer is therefore tagged with the pass that wrote it
     (torch._C._current_graph_task_id()) and reads from any other pass see an empty cell - a stale share is never added to
     a later pass's gradient (tests/test_gpu_parity.py::test_gradient_cells_survive_a_partial_backward)."""
-    __slots__ = ("_buf", "_task", "_pend", "_ptask", "_add", "_atask", "pull_reader")
+    __slots__ = ("_buf", "_task", "_pend", "_ptask", "_add", "_atask", "pull_reader", "_dg", "_dgtask")
 
     def __init__(self):
         self._buf, self._task = None, -1
@@ -1005,6 +1072,19 @@ class _SlotGradCell:
         self._add, self._atask = None, -1       # one more [N,D] addend of the pull gather (the residual branch's share)
         self.pull_reader = False                # set in forward by the state's slot-0 reader when its backward will be the pull
                                                 # form (fused geometric combine): only then is an addend worth parking
+        self._dg, self._dgtask = None, -1       # dictionary cell: the (uid, theta, gh) of the layers whose share waits for ONE launch
+
+    # One dictionary-gradient launch for all the layers that read the dictionary (dict_grad_multi_raw): every reader parks
+    # (uid view, theta, gh); the first reader in forward order - the last to run backward - runs the launch.  Pass-tagged like `buf`.
+    def park_dict(self, uid, theta, gh):
+        if self._dg is None or self._dgtask != _backward_pass_id():
+            self._dg, self._dgtask = [], _backward_pass_id()
+        self._dg.append((uid, theta, gh))
+
+    def take_dicts(self):
+        t = self._dg if self._dgtask == _backward_pass_id() else None
+        self._dg, self._dgtask = None, -1
+        return t or []
 
     def park_addend(self, t):
         self._add, self._atask = t, _backward_pass_id()

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ops import _last_contig, _ptr, _stream
+from .ops import _last_contig, _ptr, _stream, refuse_dynamic_rows
 
 
 def _wgrad(dy, x, want_bias):
@@ -38,6 +38,7 @@ class AttentionCombineFn(torch.autograd.Function):
         lib = _lib.load()
         x = _last_contig(x.float())
         N, K, D = x.shape
+        refuse_dynamic_rows("the attention combine (its products run over every row)", N)
         dev = x.device
         w_cat = torch.cat([w_ih, w_ih_r], dim=0)                       # [8K, D]
         b_cat = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r], dim=0)        # [8K]
@@ -117,6 +118,7 @@ class AttentionScanFn(torch.autograd.Function):
     def forward(ctx, x, *params):
         lib = _lib.load()
         N, K, D = x.shape
+        refuse_dynamic_rows("the attention combine (its products run over every row)", N)
         dev = x.device
         params = [t.contiguous() for t in params]
         acts = torch.empty((((N + 31) // 32) * 2 * K * 20 * 64,), dtype=torch.float32, device=dev)

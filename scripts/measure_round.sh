@@ -39,6 +39,10 @@ pmc write WRITE_SIZE
 pmc sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES
 pmc sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_ANY
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
+pmca() { name=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/pmc_$name -- $PB --combine attention --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > $R/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; }
+pmca fetch_att FETCH_SIZE
+pmca write_att WRITE_SIZE
+pmca mfma_att SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 cd $GRAFT_REPO_ROOT
 for n in default fresh b64 kpgin attention bf16 zinc_gd16 qm9 regular_b1 regular_b100 dense_peripheral; do python scripts/kstats.py $R/prof_$n 48 > $R/kstats_$n.txt 2>&1; done
 DIG=$(python -c "import bench; print(bench.csrc_digest())")
@@ -47,6 +51,8 @@ python scripts/pmc_summarize.py traffic $R/pmc_fetch $R/pmc_write $R/pmc_traffic
 mkdir -p profiles/r03 && cp $R/pmc_traffic.json profiles/r03/pmc_traffic.json && run bench_default
 python scripts/pmc_summarize.py sq $R/pmc_sq1 $R/pmc_sq1.json > /dev/null 2>&1; python scripts/pmc_summarize.py sq $R/pmc_sq2 $R/pmc_sq2.json > /dev/null 2>&1
 python scripts/pmc_summarize.py mfma $R/pmc_mfma $R/pmc_mfma.json > /dev/null 2>&1
+python scripts/pmc_summarize.py traffic $R/pmc_fetch_att $R/pmc_write_att $R/pmc_traffic_attention.json "zinc|KPGINPlus|B2048|K8|L8|h104|attention" $DIG > /dev/null 2>&1; echo "traffic attention rc=$?"
+python scripts/pmc_summarize.py mfma $R/pmc_mfma_att $R/pmc_mfma_attention.json > /dev/null 2>&1
 # (what is kept must fit the 64 MiB that travel back: the summaries above are made, the raw traces and counter dumps go)
 find $R -name "*agent_info.csv" -delete; find $R -name "*kernel_trace.csv" -delete; find $R -name "*counter_collection.csv" -delete
 du -sh $R | tail -1

@@ -1893,6 +1893,54 @@ def test_pull_gather_backward_equals_the_accumulating_one(K, L, H, graphs):
     _close_param_grads({n: pm[n] for n in ref_grads}, ref_grads, "pull body", rtol=1e-2, atol=5e-3)
 
 
+@pytest.mark.parametrize("K,L,H,graphs", [(3, 4, 32, 300), (8, 8, 104, 220), (4, 6, 64, 400)])
+def test_one_dictionary_gradient_launch_for_all_layers_equals_one_per_layer(K, L, H, graphs):
+    """ops.DICT_MULTI: every layer parks (uid view, theta, gh) and the first layer's backward runs ONE kpgnn_dict_grad_multi over
+    them, against one kpgnn_dict_grad per layer (which the body tests above pin to the oracle): same score, every parameter
+    gradient equal to fp32 summation-order accuracy (theta enters before the sums instead of after them)."""
+    from kp_gnn_amd import ops
+    from kp_gnn_amd.batch import synthetic_zinc_batch
+    dev = _dev()
+    model = _small_body("KPGINPlus", "geometric", K, L, H).to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    b = synthetic_zinc_batch(graphs, seed0=23, K=K).to(dev)
+    b.build_csr()
+    assert b.num_nodes >= 4096
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    launches = []
+    real = ops.dict_grad_multi_raw
+
+    def counting(items, n_dict):
+        launches.append(len(items))
+        return real(items, n_dict)
+
+    def grads(multi):
+        model.load_state_dict(sd)
+        ops.DICT_MULTI = multi
+        ops.dict_grad_multi_raw = counting
+        try:
+            score = model(b)
+            loss = (score.squeeze() - b.y.squeeze()).abs().mean()
+            g = torch.autograd.grad(loss, params, allow_unused=True)
+        finally:
+            ops.DICT_MULTI = True
+            ops.dict_grad_multi_raw = real
+        return score.detach().clone(), [None if t is None else t.clone() for t in g]
+
+    s1, g1 = grads(True)
+    assert launches == [L], launches                    # one launch, all L layers in it
+    s0, g0 = grads(False)
+    assert launches == [L]
+    assert torch.equal(s1, s0)
+    gscale = max(float(t.abs().max()) for t in g0 if t is not None)
+    for n, a, c in zip(names, g1, g0):
+        assert (a is None) == (c is None), n
+        if a is not None:
+            tol = 2e-5 * max(float(c.abs().max()), 0.05 * gscale) + 1e-9
+            assert float((a - c).abs().max()) <= tol, (n, float((a - c).abs().max()), tol)
+
+
 @pytest.mark.parametrize("workload,model_name,K,L,H,graphs", [("qm9", "KPGIN", 6, 3, 24, 10), ("qm9", "KPGIN", 6, 8, 120, 6),
                                                               ("zinc_gd16", "KPGINPrime", 16, 4, 96, 6)])
 def test_bench_workload_bodies_match_the_oracle(workload, model_name, K, L, H, graphs):
