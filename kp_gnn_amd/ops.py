@@ -505,7 +505,7 @@ def dict_multi_ok(uid, n_dict, theta, gh):
     dom = getattr(uid, "_kp_dom", None)
     return (dom is not None and dom.numel() == K and dom.dtype == torch.int32 and dom.is_contiguous() and dom.device == gh.device
             and uid.stride(1) == 1 and uid.dtype == torch.int32 and K <= 8 and D % 2 == 0 and D <= 128 and gh.dtype == torch.float32
-            and theta.dtype == torch.float32 and tuple(theta.shape) == (K, D) and 4 * (n_dict * 8 + 9 * 16) * D <= 160 * 1024)
+            and theta.dtype == torch.float32 and tuple(theta.shape) == (K, D) and 4 * (n_dict * 8 + 9) * D <= 160 * 1024)
 
 
 def dict_grad_multi_raw(items, n_dict):
@@ -517,7 +517,16 @@ def dict_grad_multi_raw(items, n_dict):
     D = items[0][2].shape[1]
     dev = items[0][2].device
     base = uid.data_ptr()
-    assert len(items) <= 16 and all(it[0].data_ptr() == base and it[0].stride(0) == uid.stride(0) and it[0].shape[0] == N for it in items)
+    one = all(it[0].data_ptr() == base and it[0].stride(0) == uid.stride(0) and it[0].shape[0] == N for it in items)
+    if not one or len(items) > 16 or 4 * (n_dict * K + 9 * len(items)) * D > 160 * 1024:
+        # (different id matrices, more layers than the kernel takes, or a table + per-layer totals beyond the LDS: one launch per layer)
+        total = None
+        for u, th, gh in items:
+            g = dict_grad_raw(u, n_dict, th, gh)
+            if g is None:
+                raise _lib.KpgnnError("kpgnn_dict_grad refused a share that was parked for kpgnn_dict_grad_multi")
+            total = g if total is None else total + g
+        return total
     keep = []
     d = _lib.DictGradMultiDesc()
     d.N, d.D, d.n_dict, d.L = N, D, n_dict, len(items)
