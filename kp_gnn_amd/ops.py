@@ -773,8 +773,6 @@ class KHopAggregate(torch.autograd.Function):
         # is a view of (or None): its other readers' gradients are then collected in one buffer (see khop_aggregate)
         ctx.cells = cells if xs else None
         ctx.x_cell = cells if (not xs and cells is not None) else None
-        if ctx.cells:       # (the unfused epilogue - attention combine - hands back a node-major [N,k,D] gradient: no pull form)
-            ctx.cells[0].pull_reader = bool(PULL_GATHER and mode == MODE_GINPLUS and theta is not None and eps is None)
         _require_cuda(x, table0, tablek, periph, eps, theta, xbias, ptab, uid, *xs)
         ctx.n_slots = len(xs)
         bf16 = False
@@ -787,6 +785,9 @@ class KHopAggregate(torch.autograd.Function):
             # (k_act > 1: the single-hop first layer reads the raw input embedding once - nothing to save, and its rounding
             #  is what the ill-conditioned gradients of the input encoders' scalar gates feel first)
             xs = [bf16_shadow(t) if bf16 else t.float() for t in xs]
+            if ctx.cells:   # will this reader's backward be the pull form?  (not with the unfused epilogue - the attention combine hands
+                            #  back a node-major [N,k,D] gradient - and not with bf16 storage, whose dL/dS is bf16)
+                ctx.cells[0].pull_reader = bool(PULL_GATHER and mode == MODE_GINPLUS and theta is not None and eps is None and not bf16)
             # the kernel reads every hop slot with ONE row stride (x_sn): row-strided slots (column slices of the bodies'
             # jumping-knowledge buffer) are read where they are; only mixed layouts are copied
             if any(t.stride(1) != 1 for t in xs) or len({t.stride(0) for t in xs}) != 1:
