@@ -835,11 +835,12 @@ int kpgnn_attn_bwd(const kpgnn_attn_desc* d, kpgnn_stream_t stream);
  * index 0 = forward, 1 = reverse; reference layers/combine.py:17).
  *   fwd: hsum, w, out as kpgnn_attn_fwd; acts in the kernel's own lane-contiguous layout; w_pad [64, D] = the two
  *        W_ih with the hidden size padded to 8 (row dir*32 + gate*8 + unit, zero rows for unit >= K).
- *   bwd: ds as kpgnn_attn_bwd; dgin [N*K, 64] and hprev [N*K, 16] in the padded layout (column dir*32 + gate*8 + unit /
- *        dir*8 + unit, zeros in the padding); then the COMPLETE dx[n,t,:] = w[n,t] gout[n,:] + dgin[(n,t),:] w_pad in one
- *        launch (w_pad from the forward).  dW_pad = dgin^T x, db_pad = sum dgin, dW_hh_pad = dgin^T hprev are plain
- *        weight-gradient products (kpgnn_linear_wgrad); kpgnn_attn_scan_unpad drops the padding:
- *        dw [2,4K,D], db [2,4K], dwhh [2,4K,K] from dw_pad [64,D], db_pad [64], dwhh_pad [64,16]. */
+ *   bwd: ds as kpgnn_attn_bwd; dgin [N*K, 64] in the padded layout (column dir*32 + gate*8 + unit, zeros in the padding);
+ *        dwhh_pad [2,32,8] = the recurrent weight gradient sum dg h_prev^T, taken inside the walk (the one product that contracts
+ *        over nodes: operands transposed through LDS per wave); then the COMPLETE dx[n,t,:] = w[n,t] gout[n,:] +
+ *        dgin[(n,t),:] w_pad in one launch (w_pad from the forward).  dW_pad = dgin^T x and db_pad = sum dgin are a plain
+ *        weight-gradient product (kpgnn_linear_wgrad); kpgnn_attn_scan_unpad drops the padding:
+ *        dw [2,4K,D], db [2,4K], dwhh [2,4K,K] from dw_pad [64,D], db_pad [64], dwhh_pad [2,32,8]. */
 typedef struct kpgnn_attn_scan_desc {
     int32_t N, K, D;
     const float* x; int64_t x_sn, x_sk;     /* device [N,K,D], 16-byte aligned, strides multiples of 4 */
@@ -857,7 +858,8 @@ typedef struct kpgnn_attn_scan_desc {
     float* dx;                              /* device [N,K,D] contiguous, complete */
     float* ds;                              /* device [N,K] workspace */
     float* dgin;                            /* device [N*K,64] */
-    float* hprev;                           /* device [N*K,16] */
+    float* whh_slab;                        /* device workspace, ceil(N/32) * 512 floats: per-tile partials of dW_hh */
+    float* dwhh_pad;                        /* device [2,32,8] out: dW_hh of both directions, hidden size padded to 8 */
 } kpgnn_attn_scan_desc;
 
 int kpgnn_attn_scan_fwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t stream);

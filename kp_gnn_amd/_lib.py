@@ -188,7 +188,7 @@ class AttnScanDesc(ctypes.Structure):
         ("x", c_vp), ("x_sn", c_i64), ("x_sk", c_i64),
         ("w_ih", c_vp * 2), ("w_hh", c_vp * 2), ("b_ih", c_vp * 2), ("b_hh", c_vp * 2),
         ("acts", c_vp), ("hsum", c_vp), ("w", c_vp), ("out", c_vp), ("w_pad", c_vp),
-        ("gout", c_vp), ("dx", c_vp), ("ds", c_vp), ("dgin", c_vp), ("hprev", c_vp),
+        ("gout", c_vp), ("dx", c_vp), ("ds", c_vp), ("dgin", c_vp), ("whh_slab", c_vp), ("dwhh_pad", c_vp),
     ]
 
 

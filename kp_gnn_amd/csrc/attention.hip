@@ -197,14 +197,14 @@ __global__ void __launch_bounds__(kBlock) attn_lstm_bwd_kernel(const AtParams p)
 //   * BPTT's dh_{t-1} = W_hh^T dg is 16 instructions whose B operands are the lane's own 16 dg values; rows 0..7
 //     of the result land in accumulator registers 0..3 as the lane's own four units.
 // Padded units (>= K) have zero weights and biases: c = h = 0 for them, and their dg is masked.  The activations
-// saved for BPTT are written lane-contiguous ([tile][dir][t][20][64], 256 B per store instruction); dgin / hprev
-// leave in the padded layout [N*K, 64] / [N*K, 16] (16-B stores) that the weight-gradient and dX products read.
+// saved for BPTT are written lane-contiguous ([tile][dir][t][20][64], 256 B per store instruction); dgin leaves in the
+// padded layout [N*K, 64] (16-B stores) that the weight-gradient and dX products read; dW_hh is taken inside the walk.
 struct ScanParams {
     int N, K, D;
     const float* x; int64_t x_sn, x_sk;
     const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
     float* acts; float* hsum; float* w_pad;
-    const float* ds; float* dgin; float* hprev;
+    const float* ds; float* dgin; float* whh_slab;
 };
 
 constexpr int kScanThreads = 256;                    // 2 node tiles x 2 directions
@@ -371,6 +371,16 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
         for (int q = 0; q < 20; ++q) buf[1][q] = b[q * 64];
     }
     float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    // dW_hh[q][r] = sum over (node, slot) of dg[q] h_prev[r] is a contraction over NODES - over lanes - so this one product
+    // needs its operands transposed: a wave parks dg (32 gate rows) and h_prev (8 rows) of its 32 nodes in LDS, node-minor,
+    // and reads them back with lane = row: 16 matrix instructions (two nodes each) per slot into ONE accumulator it keeps for the
+    // whole walk.  (The separate weight-gradient launch this replaces re-read dgin and an hprev tensor: 33 us + a reduce.)
+    __shared__ float tr_all[kScanThreads / 64][40 * 33];
+    float* tr = tr_all[wv];
+    const float okf = (int64_t)tile * 32 + node < p.N ? 1.f : 0.f;      // (lanes past N recompute node N-1: counted once)
+    f32x16 accw;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accw[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         const int s = K - 1 - i;
@@ -404,7 +414,23 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
 #pragma unroll
             for (int ty = 0; ty < 4; ++ty)
                 *reinterpret_cast<float4*>(dgo + ty * 8) = make_float4(dg[4 * ty], dg[4 * ty + 1], dg[4 * ty + 2], dg[4 * ty + 3]);
-            *reinterpret_cast<float4*>(p.hprev + (n * K + t) * 16 + dir * 8 + 4 * half) = make_float4(hp[0], hp[1], hp[2], hp[3]);
+        }
+        if (s > 0) {                                   // (the first visited slot has h_prev = 0: nothing to add)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tr[((j >> 2) * 8 + half * 4 + (j & 3)) * 33 + node] = dg[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tr[(32 + half * 4 + u) * 33 + node] = hp[u] * okf;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float a = tr[m * 33 + 2 * q + half];
+                const float b = m < 8 ? tr[(32 + m) * 33 + 2 * q + half] : 0.f;
+                accw = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accw, 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (s > 0) {
             f32x16 acc;
@@ -415,6 +441,11 @@ __global__ void __launch_bounds__(kScanThreads) attn_scan_bwd_kernel(const ScanP
 #pragma unroll
             for (int u = 0; u < 4; ++u) dh[u] = acc[u];
         }
+    }
+    if (m < 8) {                                       // this wave's partial [32 gate rows][8 units]: slab row = tile, added in tile order
+        float* o = p.whh_slab + ((int64_t)tile * 2 + dir) * 256 + m;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[((v >> 2) * 8 + half * 4 + (v & 3)) * 8] = accw[v];
     }
 }
 
@@ -538,7 +569,7 @@ __global__ void __launch_bounds__(256) attn_unpad_kernel(const float* dw_pad, co
             db[row] = db_pad[dir * 32 + g * 8 + u];
         } else {
             const int j = i - n_w - n_b, c = j % K, row = j / K, dir = row / (4 * K), g = (row % (4 * K)) / K, u = row % K;
-            dwhh[j] = dwhh_pad[(dir * 32 + g * 8 + u) * 16 + dir * 8 + c];
+            dwhh[j] = dwhh_pad[(dir * 32 + g * 8 + u) * 8 + c];
         }
     }
 }
@@ -635,10 +666,10 @@ int check_scan(const kpgnn_attn_scan_desc* d, bool bwd) {
     KPGNN_REQUIRE((((uintptr_t)d->x) & 15) == 0 && d->x_sn % 4 == 0 && d->x_sk % 4 == 0, "attn_scan: x must be 16-byte aligned with strides that are multiples of 4");
     for (int q = 0; q < 2; ++q) KPGNN_REQUIRE(d->w_ih[q] && d->w_hh[q] && d->b_ih[q] && d->b_hh[q], "attn_scan: NULL parameter pointer");
     if (bwd) {
-        KPGNN_REQUIRE(d->gout && d->dx && d->ds && d->dgin && d->hprev, "attn_scan_bwd: NULL pointer");
+        KPGNN_REQUIRE(d->gout && d->dx && d->ds && d->dgin && d->whh_slab && d->dwhh_pad, "attn_scan_bwd: NULL pointer");
         KPGNN_REQUIRE(d->w_pad != nullptr, "attn_scan_bwd: NULL w_pad");
-        KPGNN_REQUIRE(((((uintptr_t)d->dgin) | ((uintptr_t)d->hprev) | ((uintptr_t)d->gout) | ((uintptr_t)d->dx)) & 15) == 0,
-                      "attn_scan_bwd: dgin / hprev / gout / dx must be 16-byte aligned");
+        KPGNN_REQUIRE(((((uintptr_t)d->dgin) | ((uintptr_t)d->gout) | ((uintptr_t)d->dx)) & 15) == 0,
+                      "attn_scan_bwd: dgin / gout / dx must be 16-byte aligned");
     } else {
         KPGNN_REQUIRE(d->out && d->w_pad, "attn_scan_fwd: NULL out / w_pad");
     }
@@ -648,7 +679,7 @@ int check_scan(const kpgnn_attn_scan_desc* d, bool bwd) {
 void fill_scan(const kpgnn_attn_scan_desc* d, ScanParams* q, AtParams* p, kpgnn_attn_desc* a) {
     q->N = d->N; q->K = d->K; q->D = d->D; q->x = d->x; q->x_sn = d->x_sn; q->x_sk = d->x_sk;
     for (int i = 0; i < 2; ++i) { q->w_ih[i] = d->w_ih[i]; q->w_hh[i] = d->w_hh[i]; q->b_ih[i] = d->b_ih[i]; q->b_hh[i] = d->b_hh[i]; }
-    q->acts = d->acts; q->hsum = d->hsum; q->w_pad = d->w_pad; q->ds = d->ds; q->dgin = d->dgin; q->hprev = d->hprev;
+    q->acts = d->acts; q->hsum = d->hsum; q->w_pad = d->w_pad; q->ds = d->ds; q->dgin = d->dgin; q->whh_slab = d->whh_slab;
     *a = kpgnn_attn_desc{};
     a->N = d->N; a->K = d->K; a->D = d->D; a->x = d->x; a->x_sn = d->x_sn; a->x_sk = d->x_sk;
     a->hsum = d->hsum; a->w = d->w; a->out = d->out; a->gout = d->gout; a->dx = d->dx; a->ds = d->ds;
@@ -730,6 +761,8 @@ extern "C" int kpgnn_attn_scan_bwd(const kpgnn_attn_scan_desc* d, kpgnn_stream_t
         default: hipLaunchKernelGGL(attn_scan_bwd_kernel<8>, grid, blk, 0, s, q); break;
     }
     KPGNN_LAUNCH_CHECK("attn_scan_bwd_kernel");
+    rc = slab_reduce(d->whh_slab, ntiles, 512, d->dwhh_pad, 512, nullptr, 0, nullptr, s);     // dW_hh (padded): tiles in order
+    if (rc != KPGNN_OK) return rc;
     DxParams x;
     x.R = (int64_t)d->N * d->K; x.K = d->K; x.D = d->D;
     x.dgin = d->dgin; x.w_pad = d->w_pad; x.w = d->w; x.gout = d->gout; x.dx = d->dx;

@@ -143,16 +143,17 @@ class AttentionScanFn(torch.autograd.Function):
         dx = torch.empty((N, K, D), dtype=torch.float32, device=dev)
         ds = torch.empty((N, K), dtype=torch.float32, device=dev)
         dgin = torch.empty((N * K, 64), dtype=torch.float32, device=dev)
-        hprev = torch.empty((N * K, 16), dtype=torch.float32, device=dev)
+        slab = torch.empty((((N + 31) // 32) * 512,), dtype=torch.float32, device=dev)
+        dwhh_pad = torch.empty((2, 32, 8), dtype=torch.float32, device=dev)
         hsum = torch.empty((1,), dtype=torch.float32, device=dev)       # unused in backward
         d = _scan_desc(x, params, acts, hsum, w)
         d.w_pad = w_pad.data_ptr()
-        d.gout, d.dx, d.ds, d.dgin, d.hprev = gout.data_ptr(), dx.data_ptr(), ds.data_ptr(), dgin.data_ptr(), hprev.data_ptr()
+        d.gout, d.dx, d.ds, d.dgin = gout.data_ptr(), dx.data_ptr(), ds.data_ptr(), dgin.data_ptr()
+        d.whh_slab, d.dwhh_pad = slab.data_ptr(), dwhh_pad.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(lib.kpgnn_attn_scan_bwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_bwd")   # ds, dgin, hprev, dx
+            _lib.check(lib.kpgnn_attn_scan_bwd(ctypes.byref(d), _stream(x)), "kpgnn_attn_scan_bwd")   # ds, dgin, dwhh_pad, dx
         xf = x.reshape(N * K, D)
         dw_pad, db_pad = _wgrad(dgin, xf, True)                          # [64, D], [64]
-        dwhh_pad, _ = _wgrad(dgin, hprev, False)                         # [64, 16]
         dw = torch.empty((2, 4 * K, D), dtype=torch.float32, device=dev)
         db = torch.empty((2, 4 * K), dtype=torch.float32, device=dev)
         dwhh = torch.empty((2, 4 * K, K), dtype=torch.float32, device=dev)
