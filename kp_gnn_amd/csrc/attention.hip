@@ -187,10 +187,10 @@ __global__ void __launch_bounds__(kBlock) attn_lstm_bwd_kernel(const AtParams p)
 // direction are ONE 32-row MFMA tile in the parameter's own order (i, f, g, o blocks of 8), and the products are
 // taken transposed - gates x nodes = W (32 x D) . x_t^T (D x 32) - so that lane l ends up with node l & 31 and,
 // in accumulator register r, gate r / 4 of unit 4 (l >> 5) + r % 4: the four gates of four units of its node, which
-// is what the recurrence needs.  Nothing is exchanged between lanes:
+// is what the recurrence needs.  The recurrence's three products exchange nothing between lanes:
 //   * B operand of the input product = 8 consecutive floats of the lane's node row, straight from global memory
 //     (lane (node, half) feeds columns 16 ks + 8 half + e of k-step ks), split in registers into three bf16 pieces;
-//     A = the weight row of gate l & 31, same columns, split once and resident; six products per k-step on
+//     A = the weight row of gate l & 31, same columns, split once per block into LDS fragments; six products per k-step on
 //     v_mfma_f32_32x32x16_bf16 give the fp32 product (bf3.h).
 //   * the recurrent product W_hh h_{t-1} is 4 more instructions on the same accumulators: the B operand of the
 //     i-th one is the lane's OWN h of unit 4 half + i.
@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(kBlock) attn_lstm_bwd_kernel(const AtParams p)
 //     of the result land in accumulator registers 0..3 as the lane's own four units.
 // Padded units (>= K) have zero weights and biases: c = h = 0 for them, and their dg is masked.  The activations
 // saved for BPTT are written lane-contiguous ([tile][dir][t][20][64], 256 B per store instruction); dgin leaves in the
-// padded layout [N*K, 64] (16-B stores) that the weight-gradient and dX products read; dW_hh is taken inside the walk.
+// padded layout [N*K, 64] (16-B stores) that the weight-gradient and dX products read.  The one product that contracts over
+// NODES - dW_hh = sum dg h_prev^T - is taken inside the BPTT walk from operands a wave transposes through LDS.
 struct ScanParams {
     int N, K, D;
     const float* x; int64_t x_sn, x_sk;
