@@ -74,26 +74,37 @@ template <int VEC> __device__ __forceinline__ void stv(float* p, const float (&v
     *reinterpret_cast<typename VT<VEC>::T*>(p) = t;
 }
 
-template <int G, int VEC>
+// (KMAX: the slots' rows of a node are requested together, before the softmax arithmetic - a load per loop iteration made the
+//  weighted sum a chain of K round trips per node)
+template <int G, int VEC, int KMAX>
 __global__ void __launch_bounds__(kBlock) attn_apply_fwd_kernel(const AtParams p, int K) {
     const int sg = threadIdx.x / G, sl = threadIdx.x % G;
     const int c0 = sl * VEC;
     const bool col_ok = c0 < p.D;
+    const int cc = col_ok ? c0 : 0;
     constexpr int NODES = kBlock / G;
     for (int64_t n = (int64_t)blockIdx.x * NODES + sg; n < p.N; n += (int64_t)gridDim.x * NODES) {
-        float sc[16], m = -INFINITY, den = 0.f;
-        for (int t = 0; t < K; ++t) { sc[t & 15] = p.hsum[n * K + t] + p.hsum[((int64_t)p.N + n) * K + t]; m = fmaxf(m, sc[t & 15]); }
-        for (int t = 0; t < K; ++t) { sc[t & 15] = __expf(sc[t & 15] - m); den += sc[t & 15]; }
+        float xv[KMAX][VEC];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) ldv<VEC>(p.x + n * p.x_sn + (int64_t)(t < K ? t : 0) * p.x_sk + cc, xv[t]);
+        float sc[KMAX], m = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int tt = t < K ? t : 0;
+            sc[t] = p.hsum[n * K + tt] + p.hsum[((int64_t)p.N + n) * K + tt];
+            if (t < K) m = fmaxf(m, sc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) { sc[t] = t < K ? __expf(sc[t] - m) : 0.f; den += sc[t]; }
         const float inv = 1.0f / den;
         float acc[VEC];
         for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-        for (int t = 0; t < K; ++t) {
-            const float wt = sc[t & 15] * inv;
-            if (sl == 0) p.w[n * K + t] = wt;
-            if (col_ok) {
-                float v[VEC];
-                ldv<VEC>(p.x + n * p.x_sn + (int64_t)t * p.x_sk + c0, v);
-                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(wt, v[q], acc[q]);
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t < K) {
+                const float wt = sc[t] * inv;
+                if (sl == 0) p.w[n * K + t] = wt;
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(wt, xv[t][q], acc[q]);
             }
         }
         if (col_ok) stv<VEC>(p.out + n * p.D + c0, acc);
@@ -101,32 +112,39 @@ __global__ void __launch_bounds__(kBlock) attn_apply_fwd_kernel(const AtParams p
 }
 
 // ---- backward of softmax + weighted sum: dw_t = <gout, x_t>, dx_direct = w_t gout, ds = w (dw - sum w dw)
-template <int G, int VEC>
+template <int G, int VEC, int KMAX>
 __global__ void __launch_bounds__(kBlock) attn_apply_bwd_kernel(const AtParams p, int K) {
     const int sg = threadIdx.x / G, sl = threadIdx.x % G;
     const int c0 = sl * VEC;
     const bool col_ok = c0 < p.D;
+    const int cc = col_ok ? c0 : 0;
     constexpr int NODES = kBlock / G;
     for (int64_t n = (int64_t)blockIdx.x * NODES + sg; n < p.N; n += (int64_t)gridDim.x * NODES) {
+        float xv[KMAX][VEC];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) ldv<VEC>(p.x + n * p.x_sn + (int64_t)(t < K ? t : 0) * p.x_sk + cc, xv[t]);
         float go[VEC];
         for (int q = 0; q < VEC; ++q) go[q] = 0.f;
         if (col_ok) ldv<VEC>(p.gout + n * p.D + c0, go);
-        float dw[16], wt[16], dot = 0.f;
-        for (int t = 0; t < K; ++t) {
+        float dw[KMAX], wt[KMAX], dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) wt[t] = p.w[n * K + (t < K ? t : 0)];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
             float part = 0.f;
-            wt[t & 15] = p.w[n * K + t];
-            if (col_ok) {
-                float v[VEC], d1[VEC];
-                ldv<VEC>(p.x + n * p.x_sn + (int64_t)t * p.x_sk + c0, v);
-                for (int q = 0; q < VEC; ++q) { part = fmaf(go[q], v[q], part); d1[q] = wt[t & 15] * go[q]; }
+            if (t < K && col_ok) {
+                float d1[VEC];
+                for (int q = 0; q < VEC; ++q) { part = fmaf(go[q], xv[t][q], part); d1[q] = wt[t] * go[q]; }
                 if (p.dx) stv<VEC>(p.dx + (n * K + t) * (int64_t)p.D + c0, d1);    // (the scan form adds it in its dX product)
             }
             for (int off = G / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);   // stays inside the sub-group
-            dw[t & 15] = part;
-            dot = fmaf(wt[t & 15], part, dot);
+            dw[t] = part;
+            dot = t < K ? fmaf(wt[t], part, dot) : dot;
         }
-        if (sl == 0)
-            for (int t = 0; t < K; ++t) p.ds[n * K + t] = wt[t & 15] * (dw[t & 15] - dot);
+        if (sl == 0) {
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) if (t < K) p.ds[n * K + t] = wt[t] * (dw[t] - dot);
+        }
     }
 }
 
@@ -633,8 +651,10 @@ int launch_apply_fwd(const kpgnn_attn_desc* d, const AtParams& p, hipStream_t s)
     int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
     const int64_t cap = (int64_t)device_facts().cu_count * 8;
     if (nb > cap) nb = cap;
-#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
-                       else hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
+#define KP_AP(GG) do { if (vec == 4 && K <= 8) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 4, 8>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else if (vec == 4) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 4, 16>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else if (K <= 8) hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 1, 8>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else hipLaunchKernelGGL((attn_apply_fwd_kernel<GG, 1, 16>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
     switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
 #undef KP_AP
     KPGNN_LAUNCH_CHECK("attn_apply_fwd_kernel");
@@ -650,8 +670,10 @@ int launch_apply_bwd(const kpgnn_attn_desc* d, const AtParams& p, hipStream_t s)
     int64_t nb = ((int64_t)d->N + (kBlock / g) - 1) / (kBlock / g);
     const int64_t cap = (int64_t)device_facts().cu_count * 8;
     if (nb > cap) nb = cap;
-#define KP_AP(GG) do { if (vec == 4) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 4>), dim3((unsigned)nb), blk, 0, s, p, K); \
-                       else hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 1>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
+#define KP_AP(GG) do { if (vec == 4 && K <= 8) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 4, 8>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else if (vec == 4) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 4, 16>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else if (K <= 8) hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 1, 8>), dim3((unsigned)nb), blk, 0, s, p, K); \
+                       else hipLaunchKernelGGL((attn_apply_bwd_kernel<GG, 1, 16>), dim3((unsigned)nb), blk, 0, s, p, K); } while (0)
     switch (g) { case 4: KP_AP(4); break; case 8: KP_AP(8); break; case 16: KP_AP(16); break; case 32: KP_AP(32); break; default: KP_AP(64); break; }
 #undef KP_AP
     KPGNN_LAUNCH_CHECK("attn_apply_bwd_kernel");
